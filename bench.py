@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""Benchmark of the CILRS hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one synthetic batch: forward + loss + backward +
+[gradient all-reduce] + Adam for BASELINE.json configs[1] ("CILRS training batch=128, 200x88 RGB,
+ResNet-34, Adam lr=2e-4, fp32"; Config A of SURVEY.md).  Inputs are resident in HBM before the
+timed region.  N > 1 is launched by torch.distributed.run, one rank per GPU (weak scaling: 128
+frames per GPU, RCCL all-reduce of the gradient arena overlapped with backward).
+
+Prints ONE JSON line (rank 0).  Besides the driver's contract it carries
+  roofline      dominant kernel family (implicit-GEMM conv), hipEvent-timed on the launch stream
+  cpu_baseline  the CPU oracle (torch fp32, the reference's own arithmetic) on this host's cores
+  infer_ms      single-frame inference latency (predict_controls path), median
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "cilrs-autonomous-driving-carla_amd"))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+TRAIN_GFLOP_PER_FRAME = 8.39      # BASELINE.md section 2 (fwd 2.798 x 3)
+PEAK_F32_MATRIX_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0
+
+
+def synthetic_batch(batch, seed, device):
+    """ImageNet-normalised U{0..255} frames, speed ~ U[0,1), command ~
+    U{0..3}, targets steer ~ U[-1,1], throttle/brake ~ U[0,1]."""
+    g = torch.Generator().manual_seed(seed)
+    u8 = torch.randint(0, 256, (batch, 88, 200, 3), generator=g, dtype=torch.uint8)
+    img = u8.float().div(255.0).permute(0, 3, 1, 2)
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    img = ((img - mean) / std).contiguous()
+    speed = torch.rand(batch, generator=g)
+    cmd = torch.randint(0, 4, (batch,), generator=g)
+    tgt = torch.rand(batch, 3, generator=g)
+    tgt[:, 0] = tgt[:, 0] * 2 - 1
+    return [t.to(device) for t in (img, speed, cmd, tgt)], u8
+
+
+def cpu_baseline(batch, steps=2):
+    """The oracle (oracle/cilrs_oracle.py) timed on this host: `steps` Config-A train steps at
+    the same batch after one warm-up, plus 20 single-frame eval forwards."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import cilrs_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    m = O.build_oracle(0)
+    opt = O.make_optimizer(m, O.CONFIG_A)
+    imgs, spds, cmds, tgts = O.synthetic_batch(batch, seed=1)[:4]
+    O.train_step(m, opt, O.CONFIG_A, imgs, spds, cmds, tgts)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        O.train_step(m, opt, O.CONFIG_A, imgs, spds, cmds, tgts)
+    dt = time.perf_counter() - t0
+    m.eval()
+    with torch.no_grad():
+        for _ in range(3):
+            m(imgs[:1], spds[:1], cmds[:1])
+        t1 = time.perf_counter()
+        for _ in range(20):
+            m(imgs[:1], spds[:1], cmds[:1])
+        infer_ms = (time.perf_counter() - t1) / 20 * 1e3
+    return dict(value=round(batch * steps / dt, 2), unit="frames/s", cores=cores, kind="port",
+                sample=f"{steps} Config-A train steps at B={batch} (after 1 warm-up) with "
+                       f"torch.set_num_threads({cores}); infer = mean of 20 B=1 eval forwards",
+                infer_ms=round(infer_ms, 3))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=128, help="frames per GPU")
+    ap.add_argument("--config", default="A", choices=["A", "B"])
+    ap.add_argument("--profile-steps", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    pg = None
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+        pg = dist.group.WORLD
+    assert world == args.gpus or world == 1 and args.gpus == 1, \
+        f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+
+    from cilrs_mi355 import CILRS, CONFIG_A, CONFIG_B, Trainer, TrainConfig
+    from cilrs_mi355.parallel import broadcast_parameters
+    torch.manual_seed(0)
+    cfg = CONFIG_A if args.config == "A" else TrainConfig(**{**CONFIG_B.__dict__})
+    model = CILRS(4, dropout=cfg.dropout).to(dev)
+    trainer = Trainer(model, cfg, process_group=pg)
+    if world > 1:
+        broadcast_parameters(trainer.eng, pg)
+    batch, u8 = synthetic_batch(args.batch, 1 + rank, dev)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        trainer.train_step(*batch)
+    sync()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        trainer.train_step(*batch)
+    e1.record()
+    sync()
+    wall = time.perf_counter() - t0
+    t = torch.tensor([wall], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall = float(t.item())
+    loss_total = trainer.losses()["total"]
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    frames = args.batch * world * args.steps
+    value = frames / wall
+    out = {
+        "metric": "frames/sec CILRS train batch=128",
+        "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(wall / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"CILRS ResNet-34 train step (fwd+loss+bwd+Adam), Config "
+                               f"{args.config}, 200x88 RGB, B={args.batch}/GPU, fp32",
+                   "global_batch": args.batch * world,
+                   "parallelism": f"dp{world}" if world > 1 else "single"},
+        "device_ms_per_step": round(e0.elapsed_time(e1) / args.steps, 3),
+        "final_loss": round(loss_total, 6),
+        "step_tflops": round(value * TRAIN_GFLOP_PER_FRAME / 1e3 / world, 2),
+        "step_frac_of_f32_matrix_peak": round(
+            value * TRAIN_GFLOP_PER_FRAME / 1e3 / world / PEAK_F32_MATRIX_TFLOPS, 4),
+    }
+
+    if world == 1:
+        # ---- per-kernel hipEvent timing on the launch stream (extra steps, same step fn) ----
+        pl = trainer.eng.plan(args.batch, 88, 200)
+        pl.profile_reset()
+        pl.profile(True)
+        for _ in range(args.profile_steps):
+            trainer.train_step(*batch)
+        torch.cuda.synchronize(dev)
+        table = pl.profile_table()
+        pl.profile(False)
+        fam = {}
+        for label, r in table.items():
+            f = label.split(".")[0]
+            a = fam.setdefault(f, dict(calls=0, ms=0.0, flops=0.0, bytes=0.0))
+            for k in a:
+                a[k] += r[k]
+        total_ms = sum(a["ms"] for a in fam.values())
+        igemm = dict(calls=fam.get("conv_fwd", {}).get("calls", 0) + fam.get("conv_dgrad", {}).get("calls", 0),
+                     ms=fam.get("conv_fwd", {}).get("ms", 0.0) + fam.get("conv_dgrad", {}).get("ms", 0.0),
+                     flops=fam.get("conv_fwd", {}).get("flops", 0.0) + fam.get("conv_dgrad", {}).get("flops", 0.0))
+        wg = fam.get("conv_wgrad", dict(calls=0, ms=0.0, flops=0.0))
+        dom_name, dom = ("conv_igemm_kernel (fwd+dgrad)", igemm) if igemm["ms"] >= wg["ms"] \
+            else ("conv_wgrad_kernel (+reduce)", wg)
+        ach = dom["flops"] / max(dom["ms"], 1e-9) / 1e9          # TFLOP/s
+        out["roofline"] = {
+            "kernel": dom_name, "bound": "mfma", "achieved": round(ach, 2),
+            "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_F32_MATRIX_TFLOPS, 4), "traffic": None,
+            "launches_per_step": dom["calls"] // max(args.profile_steps, 1),
+            "avg_launch_us": round(dom["ms"] / max(dom["calls"], 1) * 1e3, 2),
+            "flops_per_launch": round(dom["flops"] / max(dom["calls"], 1), 1),
+            "share_of_step": round(dom["ms"] / max(total_ms, 1e-9), 4),
+        }
+        out["kernels"] = {
+            f: {"calls_per_step": a["calls"] // max(args.profile_steps, 1),
+                "ms_per_step": round(a["ms"] / args.profile_steps, 4),
+                "tflops": round(a["flops"] / max(a["ms"], 1e-9) / 1e9, 2) if a["flops"] else None,
+                "gbs": round(a["bytes"] / max(a["ms"], 1e-9) / 1e6, 1) if a["bytes"] else None}
+            for f, a in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}
+        out["kernels_by_layer"] = {
+            l: {"ms_per_step": round(r["ms"] / args.profile_steps, 4),
+                "tflops": round(r["flops"] / max(r["ms"], 1e-9) / 1e9, 2) if r["flops"] else None}
+            for l, r in sorted(table.items()) if l.startswith("conv_")}
+
+        # ---- single-frame inference latency (predict_controls path) ----
+        from cilrs_mi355.predict import Predictor
+        pr = Predictor(model)
+        frame = u8[0].numpy()
+        for _ in range(20):
+            pr.predict_controls(frame, 25.0, 0)
+        lat = []
+        for _ in range(200):
+            t1 = time.perf_counter()
+            pr.predict_controls(frame, 25.0, 0)
+            lat.append((time.perf_counter() - t1) * 1e3)
+        lat.sort()
+        out["infer_ms"] = round(lat[len(lat) // 2], 4)
+        model.train()
+
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.batch)
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,104 @@
+"""ctypes binding of libcilrs_hip.so (C-ABI declared in include/cilrs_hip.h).
+
+The library is the product: there is NO CPU or eager-PyTorch fallback.  If the shared object is
+missing or a call fails, a RuntimeError is raised with the library's own message.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcilrs_hip.so")
+
+c_float_p = C.POINTER(C.c_float)
+vp = C.c_void_p
+sz = C.c_size_t
+i32 = C.c_int
+i64 = C.c_int64
+f32 = C.c_float
+f64 = C.c_double
+u64 = C.c_uint64
+
+
+class Buffers(C.Structure):
+    """struct cilrs_buffers"""
+    _fields_ = [("params", vp), ("grads", vp), ("bn_running", vp), ("bn_nbt", vp),
+                ("workspace", vp)]
+
+
+# symbol -> (restype, argtypes); every symbol include/cilrs_hip.h declares is listed here
+SIGNATURES = {
+    "cilrs_version": (i32, []),
+    "cilrs_last_error": (C.c_char_p, []),
+    "cilrs_num_params": (i32, []),
+    "cilrs_num_bn": (i32, []),
+    "cilrs_param_arena_floats": (sz, []),
+    "cilrs_param_count": (sz, []),
+    "cilrs_param_info": (i32, [i32, C.c_char_p, i32, C.POINTER(sz), C.POINTER(sz),
+                               C.POINTER(i32), C.POINTER(i32)]),
+    "cilrs_bn_info": (i32, [i32, C.c_char_p, i32, C.POINTER(i32), C.POINTER(sz), C.POINTER(sz)]),
+    "cilrs_bn_arena_floats": (sz, []),
+    "cilrs_net_create": (i32, [i32, i32, i32, C.POINTER(vp)]),
+    "cilrs_net_destroy": (None, [vp]),
+    "cilrs_net_workspace_bytes": (sz, [vp]),
+    "cilrs_net_forward": (i32, [vp, C.POINTER(Buffers), vp, C.c_long, C.c_long, C.c_long,
+                                C.c_long, vp, vp, i32, f32, u64, vp, vp, vp]),
+    "cilrs_net_forward_u8": (i32, [vp, C.POINTER(Buffers), vp, vp, vp, vp, vp, vp]),
+    "cilrs_loss_fwd_bwd": (i32, [vp, vp, vp, vp, i32, i32, c_float_p, f32, vp, vp, vp, vp]),
+    "cilrs_net_backward": (i32, [vp, C.POINTER(Buffers), vp, vp, i32, i32, vp]),
+    "cilrs_segment_range": (i32, [i32, C.POINTER(sz), C.POINTER(sz)]),
+    "cilrs_sqnorm_scratch_bytes": (sz, []),
+    "cilrs_grad_sqnorm": (i32, [vp, sz, f32, vp, vp, vp]),
+    "cilrs_adam_step": (i32, [vp, vp, vp, vp, sz, f64, f64, f64, f64, f64, i64, vp, f32, vp]),
+    "cilrs_scale": (i32, [vp, sz, vp, f32, vp]),
+    "cilrs_net_profile_enable": (i32, [vp, i32]),
+    "cilrs_net_profile_collect": (i32, [vp]),
+    "cilrs_net_profile_count": (i32, [vp]),
+    "cilrs_net_profile_entry": (i32, [vp, i32, C.c_char_p, i32, C.POINTER(C.c_longlong),
+                                      C.POINTER(f64), C.POINTER(f64), C.POINTER(f64)]),
+    "cilrs_net_profile_reset": (i32, [vp]),
+    "cilrs_conv2d_fwd": (i32, [vp, vp, vp] + [i32] * 11 + [vp, sz, vp]),
+    "cilrs_conv2d_dgrad": (i32, [vp, vp, vp, vp] + [i32] * 11 + [vp, sz, vp]),
+    "cilrs_conv2d_wgrad_scratch_floats": (sz, [i32] * 9),
+    "cilrs_conv2d_wgrad": (i32, [vp, vp, vp, vp] + [i32] * 10 + [vp]),
+    "cilrs_bn_partial_floats": (sz, [i32]),
+    "cilrs_bn_train_fwd": (i32, [vp, i32, i32, vp, vp, vp, vp, vp, f32, f32, vp, i32, vp, vp, vp,
+                                 vp]),
+    "cilrs_bn_eval_fwd": (i32, [vp, i32, i32, vp, vp, vp, vp, f32, vp, i32, vp, vp, vp]),
+    "cilrs_bn_bwd": (i32, [vp, vp, vp, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]),
+    "cilrs_maxpool_fwd": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
+    "cilrs_maxpool_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the bound library; raises if the HIP extension is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"CILRS HIP extension not built: {LIB_PATH} is missing. Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `make` in csrc/). "
+            "There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(L, name)          # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(rc: int):
+    if rc != 0:
+        msg = lib().cilrs_last_error()
+        raise RuntimeError("cilrs_hip: " + (msg.decode() if msg else f"error {rc}"))
+
+
+def ptr(t):
+    """Device (or host) pointer of a torch tensor, or None."""
+    return None if t is None else C.c_void_p(t.data_ptr())

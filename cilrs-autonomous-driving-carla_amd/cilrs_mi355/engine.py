@@ -1,0 +1,278 @@
+"""Host side of the HIP engine: flat parameter arenas, per-shape plans, autograd bridge.
+
+PyTorch is used here for device memory, streams and autograd plumbing only; every number is
+produced by libcilrs_hip.so (see include/cilrs_hip.h).
+
+Memory layout (all fp32, on one device):
+  * ``params``   flat arena in ``nn.Module.parameters()`` order (cilrs_param_info); each
+                 ``nn.Parameter.data`` is a VIEW into it.  Conv weights are stored OHWI and exposed
+                 as logical-OIHW permuted views (= torch channels_last memory), so
+                 ``state_dict()`` / ``load_state_dict()`` / any ``torch.optim`` work unchanged
+                 (reference contract: model/autonomous_drive.py:496-497,
+                 notebook/notebook.ipynb:533, 631-636).
+  * ``grads``    same layout; backward writes it, Adam / clip / all-reduce read it.
+  * ``bn``       running_mean / running_var arena + int64[36] num_batches_tracked.
+  * workspace    one allocation per (batch, H, W) plan holding every saved activation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+SEG_NAMES = ("heads", "layer4", "layer3", "layer2", "layer1", "stem")
+
+
+def _layout():
+    lib = L.lib()
+    params = []
+    name = C.create_string_buffer(256)
+    for i in range(lib.cilrs_num_params()):
+        off, numel, ndim = L.sz(), L.sz(), L.i32()
+        shape = (L.i32 * 4)()
+        L.check(lib.cilrs_param_info(i, name, 256, C.byref(off), C.byref(numel), C.byref(ndim),
+                                     shape))
+        params.append((name.value.decode(), off.value, numel.value,
+                       tuple(shape[k] for k in range(ndim.value))))
+    bns = []
+    for j in range(lib.cilrs_num_bn()):
+        ch, rm, rv = L.i32(), L.sz(), L.sz()
+        L.check(lib.cilrs_bn_info(j, name, 256, C.byref(ch), C.byref(rm), C.byref(rv)))
+        bns.append((name.value.decode(), ch.value, rm.value, rv.value))
+    return params, bns
+
+
+def segment_ranges():
+    """[(begin, end)] float ranges of the gradient arena, in backward execution order."""
+    lib = L.lib()
+    out = []
+    for s in range(6):
+        b, e = L.sz(), L.sz()
+        L.check(lib.cilrs_segment_range(s, C.byref(b), C.byref(e)))
+        out.append((b.value, e.value))
+    return out
+
+
+def _arena_view(arena, off, numel, shape):
+    flat = arena[off:off + numel]
+    if len(shape) == 4:                       # OHWI storage, logical OIHW
+        o, i, h, w = shape
+        return flat.view(o, h, w, i).permute(0, 3, 1, 2)
+    return flat.view(shape)
+
+
+class Plan:
+    """cilrs_net for one (batch, H, W) + its workspace."""
+
+    def __init__(self, device, batch, h, w):
+        lib = L.lib()
+        handle = L.vp()
+        L.check(lib.cilrs_net_create(batch, h, w, C.byref(handle)))
+        self.handle = handle
+        self.batch, self.h, self.w = batch, h, w
+        nbytes = lib.cilrs_net_workspace_bytes(handle)
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        assert self.workspace.data_ptr() % 256 == 0
+        self.generation = 0
+
+    def __del__(self):
+        try:
+            if self.handle:
+                L.lib().cilrs_net_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    # per-kernel hipEvent timing ------------------------------------------------------------
+    def profile(self, on: bool):
+        L.check(L.lib().cilrs_net_profile_enable(self.handle, 1 if on else 0))
+
+    def profile_reset(self):
+        L.check(L.lib().cilrs_net_profile_reset(self.handle))
+
+    def profile_table(self):
+        lib = L.lib()
+        L.check(lib.cilrs_net_profile_collect(self.handle))
+        rows = {}
+        label = C.create_string_buffer(128)
+        for i in range(lib.cilrs_net_profile_count(self.handle)):
+            calls, ms, fl, by = C.c_longlong(), L.f64(), L.f64(), L.f64()
+            L.check(lib.cilrs_net_profile_entry(self.handle, i, label, 128, C.byref(calls),
+                                                C.byref(ms), C.byref(fl), C.byref(by)))
+            rows[label.value.decode()] = dict(calls=calls.value, ms=ms.value, flops=fl.value,
+                                              bytes=by.value)
+        return rows
+
+
+class Engine:
+    def __init__(self, module):
+        lib = L.lib()                                    # raises if the extension is missing
+        named = list(module.named_parameters())
+        if not named:
+            raise RuntimeError("CILRS has no parameters")
+        device = named[0][1].device
+        if device.type != "cuda":
+            raise RuntimeError(
+                "CILRS.forward runs only on a ROCm device (model.to('cuda')): the MI355X HIP "
+                "engine has no CPU fallback")
+        self.device = device
+        self.module = module
+        self.params_layout, self.bn_layout = _layout()
+        names = [n for n, _ in named]
+        want = [p[0] for p in self.params_layout]
+        if names != want:
+            raise RuntimeError("module parameter names differ from the engine layout")
+        n_arena = lib.cilrs_param_arena_floats()
+        self.n_arena = n_arena
+        self.params = torch.zeros(n_arena, dtype=torch.float32, device=device)
+        self.grads = torch.zeros(n_arena, dtype=torch.float32, device=device)
+        self.bn = torch.zeros(lib.cilrs_bn_arena_floats(), dtype=torch.float32, device=device)
+        self.nbt = torch.zeros(len(self.bn_layout), dtype=torch.int64, device=device)
+        self.param_views, self.grad_views = [], []
+        with torch.no_grad():
+            for (name, p), (_, off, numel, shape) in zip(named, self.params_layout):
+                if p.dtype != torch.float32 or tuple(p.shape) != shape:
+                    raise RuntimeError(f"{name}: expected float32 {shape}, got {p.dtype} "
+                                       f"{tuple(p.shape)}")
+                v = _arena_view(self.params, off, numel, shape)
+                v.copy_(p.data)
+                old_grad = p.grad
+                p.data = v
+                g = _arena_view(self.grads, off, numel, shape)
+                if old_grad is not None:
+                    g.copy_(old_grad)
+                    p.grad = g
+                self.param_views.append(v)
+                self.grad_views.append(g)
+            mods = dict(module.named_modules())
+            for j, (prefix, ch, rm, rv) in enumerate(self.bn_layout):
+                bnm = mods[prefix]
+                for attr, off in (("running_mean", rm), ("running_var", rv)):
+                    v = self.bn[off:off + ch]
+                    v.copy_(getattr(bnm, attr))
+                    setattr(bnm, attr, v)          # registered buffer keeps its name
+                v = self.nbt[j]
+                v.copy_(bnm.num_batches_tracked)
+                bnm.num_batches_tracked = v
+        self._first_param = named[0][1]
+        self._last_param = named[-1][1]
+        self.plans = {}
+        self.bufs = {}
+
+    # ------------------------------------------------------------------------------------------
+    def is_attached(self) -> bool:
+        a, b = self._first_param, self._last_param
+        return (a.data_ptr() == self.params.data_ptr() and a.device == self.device
+                and b.device == self.device)
+
+    def plan(self, batch, h, w) -> Plan:
+        key = (batch, h, w)
+        pl = self.plans.get(key)
+        if pl is None:
+            pl = Plan(self.device, batch, h, w)
+            self.plans[key] = pl
+            self.bufs[key] = L.Buffers(self.params.data_ptr(), self.grads.data_ptr(),
+                                       self.bn.data_ptr(), self.nbt.data_ptr(),
+                                       pl.workspace.data_ptr())
+        return pl
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ------------------------------------------------------------------------------------------
+    def _check_inputs(self, image, speed, command):
+        if image.dim() != 4 or image.size(1) != 3:
+            raise RuntimeError(f"image must be [B,3,H,W], got {tuple(image.shape)}")
+        b = image.size(0)
+        if image.dtype != torch.float32 or speed.dtype != torch.float32:
+            raise RuntimeError("image and speed must be float32")
+        if command.dtype != torch.int64:
+            raise RuntimeError("command must be int64 (torch.long), as torch.gather requires")
+        if tuple(speed.shape) != (b,) or tuple(command.shape) != (b,):
+            raise RuntimeError("speed and command must have shape [B]")
+        for t in (image, speed, command):
+            if t.device != self.device:
+                raise RuntimeError(f"input on {t.device}, model on {self.device}")
+        return b
+
+    def run_forward(self, image, speed, command, train, dropout_p, seed):
+        """Enqueue the forward; returns (controls, pred_speed, plan)."""
+        b = self._check_inputs(image, speed, command)
+        pl = self.plan(b, image.size(2), image.size(3))
+        speed = speed.contiguous()
+        command = command.contiguous()
+        controls = torch.empty(b, 3, dtype=torch.float32, device=self.device)
+        pred_speed = torch.empty(b, dtype=torch.float32, device=self.device)
+        sn, sc, sh, sw = image.stride()
+        L.check(L.lib().cilrs_net_forward(
+            pl.handle, C.byref(self.bufs[(pl.batch, pl.h, pl.w)]), L.ptr(image), sn, sc, sh, sw,
+            L.ptr(speed), L.ptr(command), 1 if train else 0, float(dropout_p), int(seed),
+            L.ptr(controls), L.ptr(pred_speed), self._stream()))
+        if train:
+            pl.generation += 1
+        return controls, pred_speed, pl
+
+    def run_forward_u8(self, frames_u8, speed, command):
+        """uint8 RGB HWC frames [B,H,W,3] -> eval forward with fused preprocessing."""
+        if frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4 or frames_u8.size(3) != 3:
+            raise RuntimeError("frames must be uint8 [B,H,W,3]")
+        b = frames_u8.size(0)
+        pl = self.plan(b, frames_u8.size(1), frames_u8.size(2))
+        frames_u8 = frames_u8.contiguous()
+        controls = torch.empty(b, 3, dtype=torch.float32, device=self.device)
+        pred_speed = torch.empty(b, dtype=torch.float32, device=self.device)
+        L.check(L.lib().cilrs_net_forward_u8(
+            pl.handle, C.byref(self.bufs[(pl.batch, pl.h, pl.w)]), L.ptr(frames_u8),
+            L.ptr(speed.contiguous()), L.ptr(command.contiguous()), L.ptr(controls),
+            L.ptr(pred_speed), self._stream()))
+        return controls, pred_speed
+
+    def run_backward(self, pl, dcontrols, dpred_speed, seg_begin=0, seg_end=6):
+        L.check(L.lib().cilrs_net_backward(
+            pl.handle, C.byref(self.bufs[(pl.batch, pl.h, pl.w)]), L.ptr(dcontrols),
+            L.ptr(dpred_speed), seg_begin, seg_end, self._stream()))
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, image, speed, command, training, dropout_p, seed):
+        needs_graph = training and torch.is_grad_enabled() and any(
+            p.requires_grad for p in self.module.parameters())
+        if not needs_graph:
+            c, s, _ = self.run_forward(image, speed, command, training, dropout_p, seed)
+            return c, s
+        return _CILRSFunction.apply(self, image, speed, command, float(dropout_p), int(seed),
+                                    *self.module.parameters())
+
+
+class _CILRSFunction(torch.autograd.Function):
+    """Composable path: lets ``loss.backward()`` + any torch.optim drive the HIP engine
+    (notebook/notebook.ipynb:549-555).  Gradients w.r.t. the image are not produced (the
+    reference never asks for them)."""
+
+    @staticmethod
+    def forward(ctx, eng, image, speed, command, dropout_p, seed, *params):
+        controls, pred_speed, pl = eng.run_forward(image, speed, command, True, dropout_p, seed)
+        ctx.eng, ctx.pl, ctx.generation = eng, pl, pl.generation
+        ctx.n_params = len(params)
+        return controls, pred_speed
+
+    @staticmethod
+    def backward(ctx, dcontrols, dpred_speed):
+        eng, pl = ctx.eng, ctx.pl
+        if pl.generation != ctx.generation:
+            raise RuntimeError(
+                "CILRS backward: the saved activations of this forward were overwritten by a "
+                "later train-mode forward with the same input shape (one graph per shape)")
+        b = pl.batch
+        if dcontrols is None:
+            dcontrols = torch.zeros(b, 3, device=eng.device)
+        if dpred_speed is None:
+            dpred_speed = torch.zeros(b, device=eng.device)
+        eng.run_backward(pl, dcontrols.contiguous().float(), dpred_speed.contiguous().float())
+        # hand autograd its own copy: p.grad may itself alias eng.grads (accumulation would then
+        # double-count)
+        snap = eng.grads.clone()
+        grads = [_arena_view(snap, off, numel, shape)
+                 for (_, off, numel, shape) in eng.params_layout]
+        return (None, None, None, None, None, None, *grads)

@@ -1,0 +1,111 @@
+"""``CILRS`` -- drop-in for the reference's nn.Module of the same name.
+
+Mirrors model/autonomous_drive.py:361-399 (== notebook/notebook.ipynb:440-477):
+
+* ctor ``CILRS(num_commands=4, dropout=p)``;
+* ``forward(image f32[B,3,H,W], speed f32[B], command i64[B]) -> (controls f32[B,3],
+  pred_speed f32[B])`` -- a 2-tuple, exactly what ``predict_controls`` (:915-917) and
+  ``train_one_epoch`` (nb:549) unpack;
+* the strict ``state_dict`` contract (:497): 250 entries, same names / logical shapes / dtypes.
+
+The module tree holds ordinary ``nn.Conv2d`` / ``nn.BatchNorm2d`` / ``nn.Linear`` objects purely
+as parameter containers; none of their ``forward`` methods ever runs.  All arithmetic happens in
+libcilrs_hip.so (hand-written gfx950 kernels) through :mod:`cilrs_mi355.engine`; on a device
+without the HIP engine ``forward`` raises -- there is no eager/CPU fallback.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .engine import Engine
+
+
+class _NoEagerForward(nn.Module):
+    def forward(self, *a, **k):  # pragma: no cover - guard
+        raise RuntimeError("cilrs_mi355 modules are parameter containers; call CILRS.forward, "
+                           "which runs the HIP engine (no eager fallback)")
+
+
+class BasicBlock(_NoEagerForward):
+    """Parameter container with torchvision BasicBlock's attribute names."""
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+
+def _make_layer(inplanes, planes, blocks, stride):
+    down = None
+    if stride != 1 or inplanes != planes:
+        down = nn.Sequential(nn.Conv2d(inplanes, planes, 1, stride, bias=False),
+                             nn.BatchNorm2d(planes))
+    layers = [BasicBlock(inplanes, planes, stride, down)]
+    layers += [BasicBlock(planes, planes) for _ in range(1, blocks)]
+    return nn.Sequential(*layers)
+
+
+class CILRS(nn.Module):
+    def __init__(self, num_commands=4, dropout=0.0):
+        super().__init__()
+        if num_commands != 4:
+            raise ValueError("the HIP engine implements the reference's 4 command branches")
+        self.num_commands = num_commands
+        self.dropout = float(dropout)
+        # ResNet-34 trunk, re-wrapped exactly as autonomous_drive.py:366-370 does, so indices
+        # 0,1,4,5,6,7 carry the parameters and 2,3,8,9 carry none.
+        self.visual_encoder = nn.Sequential(
+            nn.Conv2d(3, 64, 7, 2, 3, bias=False), nn.BatchNorm2d(64), nn.ReLU(inplace=True),
+            nn.MaxPool2d(3, 2, 1),
+            _make_layer(64, 64, 3, 1), _make_layer(64, 128, 4, 2),
+            _make_layer(128, 256, 6, 2), _make_layer(256, 512, 3, 2),
+            nn.AdaptiveAvgPool2d((1, 1)), nn.Flatten())
+        self.speed_encoder = nn.Sequential(
+            nn.Linear(1, 128), nn.ReLU(inplace=True), nn.Dropout(dropout),
+            nn.Linear(128, 128), nn.ReLU(inplace=True))
+        self.control_branches = nn.ModuleList([
+            nn.Sequential(
+                nn.Linear(640, 256), nn.ReLU(inplace=True), nn.Dropout(dropout),
+                nn.Linear(256, 256), nn.ReLU(inplace=True), nn.Dropout(dropout),
+                nn.Linear(256, 3))
+            for _ in range(num_commands)])
+        self.speed_predictor = nn.Sequential(
+            nn.Linear(512, 256), nn.ReLU(inplace=True), nn.Dropout(dropout),
+            nn.Linear(256, 256), nn.ReLU(inplace=True),
+            nn.Linear(256, 1))
+        # torchvision.models.resnet34(pretrained=False) initialisation (:365)
+        for m in self.visual_encoder.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+        self._engine = None
+        self._dropout_calls = 0
+
+    # -- engine plumbing ---------------------------------------------------------------------
+    def _apply(self, fn, *a, **k):
+        # .to()/.cuda()/.cpu() re-create parameter storage: the flat arena must be rebuilt
+        self._engine = None
+        return super()._apply(fn, *a, **k)
+
+    def engine(self) -> Engine:
+        """The HIP engine bound to this module's parameters (built on first use)."""
+        eng = self._engine
+        if eng is None or not eng.is_attached():
+            eng = Engine(self)
+            self._engine = eng
+        return eng
+
+    # -- the reference's forward signature -----------------------------------------------------
+    def forward(self, image, speed, command):
+        eng = self.engine()
+        seed = 0
+        p = self.dropout if self.training else 0.0
+        if p > 0.0:
+            self._dropout_calls += 1
+            seed = (torch.initial_seed() * 1000003 + self._dropout_calls) & 0xFFFFFFFFFFFFFFFF
+        return eng.forward(image, speed, command, self.training, p, seed)

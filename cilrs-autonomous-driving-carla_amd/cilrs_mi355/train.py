@@ -1,0 +1,170 @@
+"""Fused training step -- the MI355X counterpart of the body of ``train_one_epoch``
+(reference notebook/notebook.ipynb:545-558): forward, loss, backward, [clip], Adam, in that
+order, all as HIP kernels on one stream with no host synchronisation (the reference's six
+``.item()`` syncs per step, nb:523-526, become one device buffer read on demand).
+
+Also the evaluation loop body (``validate``, nb:563-585) and StepLR (nb:535-536, 604).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import torch
+
+from . import _lib as L
+
+LOSS_KEYS = ("total", "control", "steer", "throttle", "brake", "speed")
+CMD_NAMES = {0: "FOLLOW", 1: "LEFT", 2: "RIGHT", 3: "STRAIGHT"}
+
+
+@dataclass
+class TrainConfig:
+    """A = documented config (README.md:98-108, configs/train_config.json:24-35; BASELINE.json);
+    B = the config the notebook actually executed (notebook/notebook.ipynb:489-502)."""
+    name: str = "A"
+    lr: float = 2e-4
+    weight_decay: float = 1e-4
+    loss: str = "mse"                                  # "mse" | "l1"
+    loss_weights: tuple = (1.0, 1.0, 1.0, 0.05)        # steer, throttle, brake, speed
+    grad_clip: float = 0.0
+    dropout: float = 0.0
+    betas: tuple = (0.9, 0.999)
+    eps: float = 1e-8
+    lr_step_size: int = 8
+    lr_gamma: float = 0.5
+
+
+CONFIG_A = TrainConfig()
+CONFIG_B = TrainConfig(name="B", lr=1e-4, loss="l1", loss_weights=(5.0, 1.0, 1.0, 0.5),
+                       grad_clip=1.0, dropout=0.5)
+
+
+class Trainer:
+    def __init__(self, model, cfg: TrainConfig = CONFIG_A, process_group=None):
+        self.model = model
+        self.cfg = cfg
+        self.eng = model.engine()
+        dev = self.eng.device
+        n = self.eng.n_arena
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.step_count = 0
+        self.epoch = 0
+        self.lr = cfg.lr
+        self.loss_buf = torch.zeros(8, dtype=torch.float32, device=dev)
+        self.clip_out = torch.zeros(2, dtype=torch.float32, device=dev)
+        self.norm_scratch = torch.empty(L.lib().cilrs_sqnorm_scratch_bytes(), dtype=torch.uint8,
+                                        device=dev)
+        self._dgrads = {}
+        self._w = (C.c_float * 4)(*cfg.loss_weights)
+        self._kind = 1 if cfg.loss == "l1" else 0
+        self._seed_calls = 0
+        self.reducer = None
+        if process_group is not None:
+            from .parallel import BucketedAllReduce
+            self.reducer = BucketedAllReduce(self.eng.grads, process_group)
+
+    # -- pieces ---------------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.eng.device).cuda_stream)
+
+    def _ensure_engine(self):
+        eng = self.model.engine()
+        if eng is not self.eng:
+            raise RuntimeError("the model was moved/re-created after the Trainer was built")
+        return eng
+
+    def loss(self, controls, targets, pred_speed, target_speed, want_grads=True):
+        """CILRSLoss (nb:514-527) / the documented MSE loss; returns device buffer [6] in
+        LOSS_KEYS order, plus (dcontrols, dpred_speed) when want_grads."""
+        b = controls.size(0)
+        dc = dp = None
+        if want_grads:
+            if b not in self._dgrads:
+                self._dgrads[b] = (torch.empty(b, 3, device=controls.device),
+                                   torch.empty(b, device=controls.device))
+            dc, dp = self._dgrads[b]
+        L.check(L.lib().cilrs_loss_fwd_bwd(
+            L.ptr(controls), L.ptr(targets.contiguous()), L.ptr(pred_speed),
+            L.ptr(target_speed.contiguous()), b, self._kind, self._w, 1.0, L.ptr(dc), L.ptr(dp),
+            L.ptr(self.loss_buf), self._stream()))
+        return self.loss_buf, dc, dp
+
+    def optimizer_step(self, grad_scale=1.0):
+        """clip_grad_norm_ (nb:553-554) + Adam.step (nb:555) over the flat arena."""
+        lib = L.lib()
+        eng, cfg = self.eng, self.cfg
+        clip_ptr = None
+        if cfg.grad_clip > 0:
+            if grad_scale != 1.0:
+                L.check(lib.cilrs_scale(L.ptr(eng.grads), eng.n_arena, None, grad_scale,
+                                        self._stream()))
+                grad_scale = 1.0
+            L.check(lib.cilrs_grad_sqnorm(L.ptr(eng.grads), eng.n_arena, cfg.grad_clip,
+                                          L.ptr(self.norm_scratch), L.ptr(self.clip_out),
+                                          self._stream()))
+            clip_ptr = L.ptr(self.clip_out)
+        self.step_count += 1
+        L.check(lib.cilrs_adam_step(L.ptr(eng.params), L.ptr(eng.grads), L.ptr(self.exp_avg),
+                                    L.ptr(self.exp_avg_sq), eng.n_arena, self.lr, cfg.betas[0],
+                                    cfg.betas[1], cfg.eps, cfg.weight_decay, self.step_count,
+                                    clip_ptr, grad_scale, self._stream()))
+
+    # -- one iteration of train_one_epoch's loop (nb:549-555) ------------------------------------
+    def train_step(self, imgs, speeds, cmds, tgts):
+        """Returns the device loss buffer [>=6] (LOSS_KEYS order); reading it is the only sync."""
+        eng = self._ensure_engine()
+        if not self.model.training:
+            self.model.train()
+        seed = 0
+        if self.cfg.dropout > 0:
+            self._seed_calls += 1
+            seed = (torch.initial_seed() * 1000003 + self._seed_calls) & 0xFFFFFFFFFFFFFFFF
+        controls, pred_speed, pl = eng.run_forward(imgs, speeds, cmds, True, self.cfg.dropout,
+                                                   seed)
+        # `speeds` is both an input and the speed head's regression target (nb:550)
+        _, dc, dp = self.loss(controls, tgts, pred_speed, speeds)
+        if self.reducer is None:
+            eng.run_backward(pl, dc, dp)
+            self.optimizer_step(1.0)
+        else:
+            self.reducer.backward_and_reduce(eng, pl, dc, dp)
+            self.optimizer_step(1.0 / self.reducer.world_size)
+        return self.loss_buf
+
+    def losses(self):
+        """Host dict of the last step's loss terms (one device->host copy)."""
+        v = self.loss_buf[:6].tolist()
+        return dict(zip(LOSS_KEYS, v))
+
+    def grad_norm(self):
+        return float(self.clip_out[0])
+
+    # -- StepLR (nb:535-536, 604) ----------------------------------------------------------------
+    def scheduler_step(self):
+        self.epoch += 1
+        self.lr = self.cfg.lr * (self.cfg.lr_gamma ** (self.epoch // self.cfg.lr_step_size))
+
+    # -- validate() (nb:563-585) -------------------------------------------------------------------
+    @torch.no_grad()
+    def validate(self, batches):
+        """mean of batch means + per-command mean |steer error|, like the reference."""
+        self.model.eval()
+        sums = torch.zeros(6, dtype=torch.float64)
+        cmd_sum = torch.zeros(4, dtype=torch.float64, device=self.eng.device)
+        cmd_cnt = torch.zeros(4, dtype=torch.float64, device=self.eng.device)
+        n = 0
+        for imgs, speeds, cmds, tgts in batches:
+            pc, ps = self.model(imgs, speeds, cmds)
+            buf, _, _ = self.loss(pc, tgts, ps, speeds, want_grads=False)
+            sums += buf[:6].double().cpu()
+            n += 1
+            serr = (pc[:, 0] - tgts[:, 0]).abs().double()
+            cmd_sum.index_add_(0, cmds, serr)
+            cmd_cnt.index_add_(0, cmds, torch.ones_like(serr))
+        out = {k: float(sums[i]) / max(n, 1) for i, k in enumerate(LOSS_KEYS)}
+        cs, cc = cmd_sum.cpu(), cmd_cnt.cpu()
+        cmd_avg = {CMD_NAMES[i]: (float(cs[i] / cc[i]) if cc[i] > 0 else float("nan"))
+                   for i in range(4)}
+        return out, cmd_avg

@@ -1,0 +1,433 @@
+// BatchNorm2d (train + eval), ReLU, residual add, MaxPool2d(3,2,1), AdaptiveAvgPool2d(1) -- forward
+// and backward -- for NHWC fp32 activations.  These are the HBM-bound pieces of the CILRS trunk
+// (SURVEY.md 2b): torchvision BasicBlock = conv-BN-ReLU-conv-BN-(+id)-ReLU, stem = conv-BN-ReLU-
+// maxpool, tail = avgpool (reference model/autonomous_drive.py:366-370).
+//
+// Semantics follow torch.nn.BatchNorm2d exactly: batch mean / BIASED variance for normalisation,
+// UNBIASED variance into running_var, momentum 0.1, eps 1e-5, num_batches_tracked += 1; like
+// torch's CPU kernels the per-channel statistics are accumulated in double from fp32 partial sums.
+//
+// Every reduction is a fixed-shape tree (per-thread rows -> LDS -> per-block partial -> serial
+// double sum over blocks): deterministic, no atomics.  Channel is the fastest index, so a wave reads
+// whole 256-B/1-KiB rows (float4 per lane) -- fully coalesced.
+#include "common.h"
+
+namespace cilrs {
+
+namespace {
+
+constexpr int kMaxPartBlocks = 512;
+
+// partial[blk][0][c] = sum_rows v1, partial[blk][1][c] = sum_rows v2
+// MODE 0: v1 = y, v2 = y*y                     (forward statistics)
+// MODE 1: v1 = g, v2 = g * (y - mean) * rstd   (backward reductions), g = dz * (z > 0 if relu)
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_colreduce_kernel(
+    const float* __restrict__ y, const float* __restrict__ dz, const float* __restrict__ z,
+    const float* __restrict__ stats, float* __restrict__ partial, const int M, const int C,
+    const int relu, const int rows_per_block) {
+    __shared__ float red[2][256 * 4];
+    const int cq = C >> 2;                 // float4 quads per row (16..128)
+    const int tpr = cq;                    // threads per row
+    const int rpi = 256 / tpr;             // rows per iteration
+    const int q = threadIdx.x % tpr, rsub = threadIdx.x / tpr;
+    const int row_begin = blockIdx.x * rows_per_block;
+    const int row_end = min(M, row_begin + rows_per_block);
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 mean = {0.f, 0.f, 0.f, 0.f}, rstd = {0.f, 0.f, 0.f, 0.f};
+    if (MODE == 1) {
+        mean = *reinterpret_cast<const f32x4*>(stats + q * 4);
+        rstd = *reinterpret_cast<const f32x4*>(stats + C + q * 4);
+    }
+    if (rsub < rpi) {
+        for (int r = row_begin + rsub; r < row_end; r += rpi) {
+            const size_t o = (size_t)r * C + q * 4;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(y + o);
+            if (MODE == 0) {
+                s1 += v;
+                s2 += v * v;
+            } else {
+                f32x4 g = *reinterpret_cast<const f32x4*>(dz + o);
+                if (relu) {
+                    const f32x4 zz = *reinterpret_cast<const f32x4*>(z + o);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) g[e] = zz[e] > 0.f ? g[e] : 0.f;
+                }
+                s1 += g;
+                s2 += g * ((v - mean) * rstd);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        red[0][threadIdx.x * 4 + e] = s1[e];
+        red[1][threadIdx.x * 4 + e] = s2[e];
+    }
+    __syncthreads();
+    // thread c (< C) sums the rpi row-subgroups for channel c in a fixed order
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float a1 = 0.f, a2 = 0.f;
+        const int qq = c >> 2, e = c & 3;
+        for (int rs = 0; rs < rpi; ++rs) {
+            a1 += red[0][(rs * tpr + qq) * 4 + e];
+            a2 += red[1][(rs * tpr + qq) * 4 + e];
+        }
+        partial[(size_t)blockIdx.x * 2 * C + c] = a1;
+        partial[(size_t)blockIdx.x * 2 * C + C + c] = a2;
+    }
+}
+
+// stats layout (floats): [0,C) mean | [C,2C) rstd | [2C,3C) w = gamma*rstd | [3C,4C) b = beta-mean*w
+__global__ void bn_fwd_finalize_kernel(const float* __restrict__ partial, const int nblk,
+                                       const int M, const int C, const float* __restrict__ gamma,
+                                       const float* __restrict__ beta, float* running_mean,
+                                       float* running_var, long long* nbt, const float momentum,
+                                       const float eps, float* __restrict__ stats) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        s1 += (double)partial[(size_t)b * 2 * C + c];
+        s2 += (double)partial[(size_t)b * 2 * C + C + c];
+    }
+    const double mean = s1 / M;
+    double var = s2 / M - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float w = gamma[c] * rstd;
+    stats[c] = (float)mean;
+    stats[C + c] = rstd;
+    stats[2 * C + c] = w;
+    stats[3 * C + c] = beta[c] - (float)mean * w;
+    if (running_mean) {
+        const double unbiased = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+    }
+    if (nbt && c == 0) *nbt += 1;
+}
+
+// eval mode: stats from the running statistics
+__global__ void bn_eval_stats_kernel(const float* __restrict__ gamma,
+                                     const float* __restrict__ beta,
+                                     const float* __restrict__ running_mean,
+                                     const float* __restrict__ running_var, const float eps,
+                                     const int C, float* __restrict__ stats) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float rstd = 1.0f / sqrtf(running_var[c] + eps);
+    const float w = gamma[c] * rstd;
+    stats[c] = running_mean[c];
+    stats[C + c] = rstd;
+    stats[2 * C + c] = w;
+    stats[3 * C + c] = beta[c] - running_mean[c] * w;
+}
+
+// z = relu?( y*w + b (+ residual) )
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ y,
+                                                       const float* __restrict__ stats,
+                                                       const float* __restrict__ residual,
+                                                       float* __restrict__ z, const size_t total4,
+                                                       const int C, const int relu) {
+    const int cq = C >> 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i % cq);
+        const f32x4 w = *reinterpret_cast<const f32x4*>(stats + 2 * C + q * 4);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(stats + 3 * C + q * 4);
+        f32x4 v = *reinterpret_cast<const f32x4*>(y + i * 4);
+        v = v * w + b;
+        if (residual) v += *reinterpret_cast<const f32x4*>(residual + i * 4);
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        *reinterpret_cast<f32x4*>(z + i * 4) = v;
+    }
+}
+
+// coef layout: [0,C) c1 = gamma*rstd | [C,2C) c2 = sum(g)/M | [2C,3C) c3 = sum(g*xhat)/M
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, const int nblk,
+                                       const int M, const int C, const float* __restrict__ gamma,
+                                       const float* __restrict__ stats, float* dgamma,
+                                       float* dbeta, float* __restrict__ coef,
+                                       const int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        s1 += (double)partial[(size_t)b * 2 * C + c];
+        s2 += (double)partial[(size_t)b * 2 * C + C + c];
+    }
+    const float db = (float)s1, dg = (float)s2;
+    dbeta[c] = accumulate ? dbeta[c] + db : db;
+    dgamma[c] = accumulate ? dgamma[c] + dg : dg;
+    coef[c] = gamma[c] * stats[C + c];
+    coef[C + c] = (float)(s1 / M);
+    coef[2 * C + c] = (float)(s2 / M);
+}
+
+// g = dz * (z>0 if relu);  dy = (g - c2 - xhat*c3) * c1;  optionally g_out = g (residual path)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
+    const float* __restrict__ dz, const float* __restrict__ z, const float* __restrict__ y,
+    const float* __restrict__ stats, const float* __restrict__ coef, float* __restrict__ dy,
+    float* __restrict__ g_out, const size_t total4, const int C, const int relu) {
+    const int cq = C >> 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i % cq);
+        const f32x4 mean = *reinterpret_cast<const f32x4*>(stats + q * 4);
+        const f32x4 rstd = *reinterpret_cast<const f32x4*>(stats + C + q * 4);
+        const f32x4 c1 = *reinterpret_cast<const f32x4*>(coef + q * 4);
+        const f32x4 c2 = *reinterpret_cast<const f32x4*>(coef + C + q * 4);
+        const f32x4 c3 = *reinterpret_cast<const f32x4*>(coef + 2 * C + q * 4);
+        f32x4 g = *reinterpret_cast<const f32x4*>(dz + i * 4);
+        if (relu) {
+            const f32x4 zz = *reinterpret_cast<const f32x4*>(z + i * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = zz[e] > 0.f ? g[e] : 0.f;
+        }
+        const f32x4 xh = (*reinterpret_cast<const f32x4*>(y + i * 4) - mean) * rstd;
+        if (g_out) *reinterpret_cast<f32x4*>(g_out + i * 4) = g;
+        *reinterpret_cast<f32x4*>(dy + i * 4) = (g - c2 - xh * c3) * c1;
+    }
+}
+
+// ---- MaxPool2d(kernel 3, stride 2, pad 1) --------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x,
+                                                          float* __restrict__ out,
+                                                          unsigned char* __restrict__ argmax,
+                                                          const int N, const int H, const int W,
+                                                          const int C, const int Ho, const int Wo) {
+    const int cq = C >> 2;
+    const size_t total = (size_t)N * Ho * Wo * cq;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i % cq);
+        size_t p = i / cq;
+        const int ow = (int)(p % Wo); p /= Wo;
+        const int oh = (int)(p % Ho);
+        const int n = (int)(p / Ho);
+        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int bi[4] = {0, 0, 0, 0};
+        bool first = true;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int h = oh * 2 - 1 + kh;
+            if (h < 0 || h >= H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int w = ow * 2 - 1 + kw;
+                if (w < 0 || w >= W) continue;
+                const f32x4 v =
+                    *reinterpret_cast<const f32x4*>(x + ((size_t)(n * H + h) * W + w) * C + q * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    // torch: first maximum in scan order wins (val > max || isnan(val))
+                    if (first || v[e] > best[e] || v[e] != v[e]) {
+                        best[e] = v[e];
+                        bi[e] = kh * 3 + kw;
+                    }
+                }
+                first = false;
+            }
+        }
+        *reinterpret_cast<f32x4*>(out + i * 4) = best;
+        if (argmax) {
+            uchar4 a;
+            a.x = (unsigned char)bi[0]; a.y = (unsigned char)bi[1];
+            a.z = (unsigned char)bi[2]; a.w = (unsigned char)bi[3];
+            *reinterpret_cast<uchar4*>(argmax + i * 4) = a;
+        }
+    }
+}
+
+// gather form: each INPUT element sums the (<= 4) windows that selected it
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dout,
+                                                          const unsigned char* __restrict__ argmax,
+                                                          float* __restrict__ dx, const int N,
+                                                          const int H, const int W, const int C,
+                                                          const int Ho, const int Wo) {
+    const int cq = C >> 2;
+    const size_t total = (size_t)N * H * W * cq;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i % cq);
+        size_t p = i / cq;
+        const int w = (int)(p % W); p /= W;
+        const int h = (int)(p % H);
+        const int n = (int)(p / H);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int kh = 0; kh < 3; ++kh) {
+            const int t = h + 1 - kh;
+            if (t < 0 || (t & 1)) continue;
+            const int oh = t >> 1;
+            if (oh >= Ho) continue;
+            for (int kw = 0; kw < 3; ++kw) {
+                const int u = w + 1 - kw;
+                if (u < 0 || (u & 1)) continue;
+                const int ow = u >> 1;
+                if (ow >= Wo) continue;
+                const size_t o = (((size_t)(n * Ho + oh) * Wo + ow) * cq + q) * 4;
+                const uchar4 a = *reinterpret_cast<const uchar4*>(argmax + o);
+                const f32x4 g = *reinterpret_cast<const f32x4*>(dout + o);
+                const int k = kh * 3 + kw;
+                if (a.x == k) acc[0] += g[0];
+                if (a.y == k) acc[1] += g[1];
+                if (a.z == k) acc[2] += g[2];
+                if (a.w == k) acc[3] += g[3];
+            }
+        }
+        *reinterpret_cast<f32x4*>(dx + i * 4) = acc;
+    }
+}
+
+// ---- AdaptiveAvgPool2d((1,1)) + Flatten ------------------------------------------------------
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restrict__ x,
+                                                          float* __restrict__ out, const int N,
+                                                          const int HW, const int C,
+                                                          const int out_ld) {
+    const int cq = C >> 2;
+    const int total = N * cq;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int q = i % cq, n = i / cq;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < HW; ++p)
+        s += *reinterpret_cast<const f32x4*>(x + ((size_t)n * HW + p) * C + q * 4);
+    const float inv = (float)HW;
+    *reinterpret_cast<f32x4*>(out + (size_t)n * out_ld + q * 4) = s / inv;
+}
+
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dout,
+                                                          float* __restrict__ dx, const int N,
+                                                          const int HW, const int C,
+                                                          const int dout_ld) {
+    const int cq = C >> 2;
+    const size_t total = (size_t)N * HW * cq;
+    const float inv = (float)HW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i % cq);
+        const int n = (int)(i / ((size_t)HW * cq));
+        const f32x4 g = *reinterpret_cast<const f32x4*>(dout + (size_t)n * dout_ld + q * 4);
+        *reinterpret_cast<f32x4*>(dx + i * 4) = g / inv;
+    }
+}
+
+int grid_for(size_t total, int per_block = 256, int cap = 4096) {
+    size_t b = (total + per_block - 1) / per_block;
+    if (b > (size_t)cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+struct ColPlan { int nblk; int rows_per_block; };
+ColPlan col_plan(int M, int C) {
+    const int rpi = 256 / (C >> 2);
+    int rows = cdiv(M, kMaxPartBlocks);
+    rows = cdiv(rows, rpi) * rpi;          // whole iterations
+    if (rows < rpi) rows = rpi;
+    ColPlan p{cdiv(M, rows), rows};
+    return p;
+}
+
+}  // namespace
+
+size_t bn_partial_floats(int C) { return (size_t)kMaxPartBlocks * 2 * C; }
+
+static int check_c(int C) {
+    CILRS_CHECK(C % 4 == 0 && C >= 4 && C <= 1024 && 256 % (C / 4) == 0,
+                "batchnorm: unsupported channel count %d", C);
+    return 0;
+}
+
+int launch_bn_train_fwd(const float* y, int M, int C, const float* gamma, const float* beta,
+                        float* running_mean, float* running_var, long long* nbt, float momentum,
+                        float eps, const float* residual, int relu, float* stats, float* partial,
+                        float* z, hipStream_t s) {
+    if (check_c(C)) return 1;
+    const ColPlan p = col_plan(M, C);
+    bn_colreduce_kernel<0><<<p.nblk, 256, 0, s>>>(y, nullptr, nullptr, nullptr, partial, M, C, 0,
+                                                  p.rows_per_block);
+    CILRS_LAUNCH_CHECK();
+    bn_fwd_finalize_kernel<<<cdiv(C, 128), 128, 0, s>>>(partial, p.nblk, M, C, gamma, beta,
+                                                        running_mean, running_var, nbt, momentum,
+                                                        eps, stats);
+    CILRS_LAUNCH_CHECK();
+    if (z) {
+        const size_t total4 = (size_t)M * C / 4;
+        bn_apply_kernel<<<grid_for(total4), 256, 0, s>>>(y, stats, residual, z, total4, C, relu);
+        CILRS_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+int launch_bn_eval_fwd(const float* y, int M, int C, const float* gamma, const float* beta,
+                       const float* running_mean, const float* running_var, float eps,
+                       const float* residual, int relu, float* stats, float* z, hipStream_t s) {
+    if (check_c(C)) return 1;
+    bn_eval_stats_kernel<<<cdiv(C, 128), 128, 0, s>>>(gamma, beta, running_mean, running_var, eps,
+                                                      C, stats);
+    CILRS_LAUNCH_CHECK();
+    const size_t total4 = (size_t)M * C / 4;
+    bn_apply_kernel<<<grid_for(total4), 256, 0, s>>>(y, stats, residual, z, total4, C, relu);
+    CILRS_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_bn_bwd(const float* dz, const float* z, const float* y, int M, int C,
+                  const float* gamma, const float* stats, int relu, float* dgamma, float* dbeta,
+                  int accumulate, float* coef, float* partial, float* dy, float* g_out,
+                  hipStream_t s) {
+    if (check_c(C)) return 1;
+    const ColPlan p = col_plan(M, C);
+    bn_colreduce_kernel<1><<<p.nblk, 256, 0, s>>>(y, dz, z, stats, partial, M, C, relu,
+                                                  p.rows_per_block);
+    CILRS_LAUNCH_CHECK();
+    bn_bwd_finalize_kernel<<<cdiv(C, 128), 128, 0, s>>>(partial, p.nblk, M, C, gamma, stats,
+                                                        dgamma, dbeta, coef, accumulate);
+    CILRS_LAUNCH_CHECK();
+    const size_t total4 = (size_t)M * C / 4;
+    bn_bwd_apply_kernel<<<grid_for(total4), 256, 0, s>>>(dz, z, y, stats, coef, dy, g_out, total4,
+                                                         C, relu);
+    CILRS_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_maxpool_fwd(const float* x, float* out, unsigned char* argmax, int N, int H, int W,
+                       int C, hipStream_t s) {
+    CILRS_CHECK(C % 4 == 0, "maxpool: C %% 4");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const size_t total = (size_t)N * Ho * Wo * (C / 4);
+    maxpool_fwd_kernel<<<grid_for(total), 256, 0, s>>>(x, out, argmax, N, H, W, C, Ho, Wo);
+    CILRS_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_maxpool_bwd(const float* dout, const unsigned char* argmax, float* dx, int N, int H,
+                       int W, int C, hipStream_t s) {
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const size_t total = (size_t)N * H * W * (C / 4);
+    maxpool_bwd_kernel<<<grid_for(total), 256, 0, s>>>(dout, argmax, dx, N, H, W, C, Ho, Wo);
+    CILRS_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_avgpool_fwd(const float* x, float* out, int N, int HW, int C, int out_ld,
+                       hipStream_t s) {
+    const int total = N * (C / 4);
+    avgpool_fwd_kernel<<<cdiv(total, 256), 256, 0, s>>>(x, out, N, HW, C, out_ld);
+    CILRS_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_avgpool_bwd(const float* dout, float* dx, int N, int HW, int C, int dout_ld,
+                       hipStream_t s) {
+    const size_t total = (size_t)N * HW * (C / 4);
+    avgpool_bwd_kernel<<<grid_for(total), 256, 0, s>>>(dout, dx, N, HW, C, dout_ld);
+    CILRS_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace cilrs

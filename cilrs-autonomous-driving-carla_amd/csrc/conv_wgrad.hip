@@ -1,0 +1,244 @@
+// Weight gradient of the convolutions / wide linear layers on the exact-f32 matrix pipe.
+//
+// Counterpart of what autograd's loss.backward() (reference notebook/notebook.ipynb:552) dispatches
+// for every nn.Conv2d / nn.Linear weight of CILRS.
+//
+// GEMM view:  dW[co][tap][ci] = sum_{p} dy[p][co] * x[pix(p,tap)][ci],   K = p = N*Ho*Wo output
+// pixels (140,800 for layer1 at B=128 ... 2,688 for layer4), M = Cout, N = Cin per filter tap.
+// Both operands are pixel-major in HBM (NHWC), i.e. the REDUCTION index is the slow one, which
+// is exactly the MFMA operand order: lane l of v_mfma_f32_32x32x2_f32 feeds A[i=l&31][k=l>>5],
+// so a wave reads 32 consecutive channels of pixel k (lanes 0-31) and of pixel k+1 (lanes 32-63)
+// from an LDS tile that is a plain copy of the NHWC rows -- conflict-free ds_read_b32, no
+// transposes anywhere.  The result lands in OHWI order, the parameters' own memory order.
+//
+// K is split across blocks (grid.z); partial slabs are summed in a fixed order by a second kernel
+// (deterministic, no float atomics).
+#include "common.h"
+
+namespace cilrs {
+
+namespace {
+
+constexpr int BKP = 32;   // pixels per K-tile
+
+template <int BT, bool TAP_UNIFORM>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a, const int Mpix,
+                                                         const int splits, const int tiles_ci,
+                                                         const int Ncols) {
+    // block tile BT(co) x BT(ci-columns); 4 waves as 2x2, wave tile (BT/2)^2
+    constexpr int WT = BT / 2, T = WT / 32;
+    constexpr int QPR = BT / 4;            // float4 quads per tile row
+    constexpr int RPP = 256 / QPR;         // rows per pass
+    constexpr int PASSES = BKP / RPP;
+    constexpr int PITCH = BT + 4;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                      // [2][BKP][PITCH]  dy tile
+    float* Bs = smem + 2 * BKP * PITCH;    // [2][BKP][PITCH]  gathered x tile
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int ntile = blockIdx.x;          // column tile: (tap, ci-tile) or flattened columns
+    const int co0 = blockIdx.y * BT;
+    const int z = blockIdx.z;
+
+    // K (pixel) range of this split, in whole K-tiles
+    const int KT = (Mpix + BKP - 1) / BKP;
+    const int per = (KT + splits - 1) / splits;
+    const int kt_begin = z * per;
+    const int kt_end = min(KT, kt_begin + per);
+
+    const int q = tid % QPR, rr = tid / QPR;
+
+    // column (tap, ci) owned by this thread's quad -- fixed across the K loop
+    int tap, ci, col0;
+    bool col_ok;
+    if constexpr (TAP_UNIFORM) {
+        tap = ntile / tiles_ci;
+        ci = (ntile - tap * tiles_ci) * BT + q * 4;
+        col0 = tap * a.Cin + (ntile - tap * tiles_ci) * BT;
+        col_ok = true;
+    } else {
+        col0 = ntile * BT;
+        const int j = col0 + q * 4;
+        tap = j / a.Cin;
+        ci = j - tap * a.Cin;
+        col_ok = j < Ncols;
+    }
+    const int kh = tap / a.KW, kw = tap - kh * a.KW;
+    const int HoWo = a.Ho * a.Wo;
+
+    f32x4 ra[PASSES], rb[PASSES];
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < PASSES; ++i) {
+            const int p = kt * BKP + rr + RPP * i;
+            f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
+            if (p < Mpix) {
+                va = *reinterpret_cast<const f32x4*>(a.dy + (size_t)p * a.dy_ld + co0 + q * 4);
+                const int n = p / HoWo, rem = p - n * HoWo;
+                const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
+                const int h = oh * a.stride - a.pad + kh, w = ow * a.stride - a.pad + kw;
+                if (col_ok && h >= 0 && w >= 0 && h < a.H && w < a.W)
+                    vb = *reinterpret_cast<const f32x4*>(
+                        a.x + (size_t)((n * a.H + h) * a.W + w) * a.x_ld + ci);
+            }
+            ra[i] = va;
+            rb[i] = vb;
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < PASSES; ++i) {
+            const int row = rr + RPP * i;
+            *reinterpret_cast<f32x4*>(As + (buf * BKP + row) * PITCH + q * 4) = ra[i];
+            *reinterpret_cast<f32x4*>(Bs + (buf * BKP + row) * PITCH + q * 4) = rb[i];
+        }
+    };
+
+    f32x16 acc[T][T];
+#pragma unroll
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+        for (int j = 0; j < T; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (kt_begin < kt_end) {
+        load_tile(kt_begin);
+        store_tile(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const bool more = kt + 1 < kt_end;
+        if (more) load_tile(kt + 1);
+        const float* Ab = As + buf * BKP * PITCH + lh * PITCH + wm * WT + l31;
+        const float* Bb = Bs + buf * BKP * PITCH + lh * PITCH + wn * WT + l31;
+#pragma unroll
+        for (int s = 0; s < BKP / 2; ++s) {
+            float af[T], bf[T];
+#pragma unroll
+            for (int i = 0; i < T; ++i) af[i] = Ab[2 * s * PITCH + i * 32];
+#pragma unroll
+            for (int j = 0; j < T; ++j) bf[j] = Bb[2 * s * PITCH + j * 32];
+#pragma unroll
+            for (int i = 0; i < T; ++i)
+#pragma unroll
+                for (int j = 0; j < T; ++j)
+                    acc[i][j] =
+                        __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) store_tile(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    // slab[z][co][col]  (col = tap*Cin + ci, OHWI order)
+    float* out = a.slabs + (size_t)z * a.Cout * Ncols;
+#pragma unroll
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+            const int col = col0 + wn * WT + j * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int co = co0 + wm * WT + i * 32 + row;
+                if (col < Ncols) out[(size_t)co * Ncols + col] = acc[i][j][r];
+            }
+        }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slabs, float* dw,
+                                                           const int splits, const size_t n_src,
+                                                           const int cin, const int cin_dst,
+                                                           const int accumulate) {
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n_src;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(idx % cin);
+        if (ci >= cin_dst) continue;
+        float v = slabs[idx];
+        for (int s = 1; s < splits; ++s) v += slabs[(size_t)s * n_src + idx];
+        const size_t o = (idx / cin) * cin_dst + ci;
+        dw[o] = accumulate ? dw[o] + v : v;
+    }
+}
+
+struct WPlan { int bt; bool uniform; int tiles_ci; int ntiles; int ncols; int splits; };
+
+WPlan plan(const WgradArgs& a) {
+    WPlan p;
+    const int taps = a.KH * a.KW;
+    const int Mpix = a.N * a.Ho * a.Wo;
+    p.ncols = taps * a.Cin;
+    p.uniform = (a.Cin % 64) == 0;
+    p.bt = (p.uniform && a.Cin % 128 == 0 && a.Cout % 128 == 0) ? 128 : 64;
+    if (p.uniform) {
+        p.tiles_ci = a.Cin / p.bt;
+        p.ntiles = taps * p.tiles_ci;
+    } else {
+        p.tiles_ci = 1;
+        p.ntiles = cdiv(p.ncols, p.bt);
+    }
+    const int tiles = p.ntiles * (a.Cout / p.bt);
+    const int KT = cdiv(Mpix, BKP);
+    int splits = cdiv(768, tiles);
+    const int max_splits = KT / 8 > 0 ? KT / 8 : 1;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    // drop empty trailing splits
+    const int per = cdiv(KT, splits);
+    splits = cdiv(KT, per);
+    p.splits = splits;
+    return p;
+}
+
+}  // namespace
+
+size_t wgrad_scratch_floats(const WgradArgs& a) {
+    const WPlan p = plan(a);
+    return (size_t)p.splits * a.Cout * p.ncols;
+}
+
+int launch_conv_wgrad(const WgradArgs& a, hipStream_t s) {
+    CILRS_CHECK(a.Cout % 64 == 0, "conv_wgrad: Cout=%d must be a multiple of 64", a.Cout);
+    CILRS_CHECK(a.Cin % 4 == 0 && a.x_ld % 4 == 0 && a.dy_ld % 4 == 0,
+                "conv_wgrad: Cin/x_ld/dy_ld must be multiples of 4");
+    CILRS_CHECK(a.slabs != nullptr, "conv_wgrad: scratch slabs missing");
+    CILRS_CHECK(((uintptr_t)a.x & 15) == 0 && ((uintptr_t)a.dy & 15) == 0 &&
+                    ((uintptr_t)a.slabs & 15) == 0,
+                "conv_wgrad: pointers must be 16-byte aligned");
+    const WPlan p = plan(a);
+    const int Mpix = a.N * a.Ho * a.Wo;
+    dim3 grid(p.ntiles, a.Cout / p.bt, p.splits);
+    const size_t lds = (size_t)4 * BKP * (p.bt + 4) * sizeof(float);
+    if (p.bt == 128) {
+        static bool attr = false;
+        if (!attr) {
+            CILRS_HIP(hipFuncSetAttribute(
+                reinterpret_cast<const void*>(&conv_wgrad_kernel<128, true>),
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr = true;
+        }
+        conv_wgrad_kernel<128, true><<<grid, 256, lds, s>>>(a, Mpix, p.splits, p.tiles_ci,
+                                                            p.ncols);
+    } else if (p.uniform) {
+        conv_wgrad_kernel<64, true><<<grid, 256, lds, s>>>(a, Mpix, p.splits, p.tiles_ci,
+                                                           p.ncols);
+    } else {
+        conv_wgrad_kernel<64, false><<<grid, 256, lds, s>>>(a, Mpix, p.splits, p.tiles_ci,
+                                                            p.ncols);
+    }
+    CILRS_LAUNCH_CHECK();
+    const size_t n_src = (size_t)a.Cout * p.ncols;
+    const int blocks = (int)((n_src + 255) / 256 < 1024 ? (n_src + 255) / 256 : 1024);
+    wgrad_reduce_kernel<<<blocks, 256, 0, s>>>(a.slabs, a.dw, p.splits, n_src, a.Cin, a.Cin_dst,
+                                               a.accumulate);
+    CILRS_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace cilrs

@@ -1,0 +1,1015 @@
+// Network plan + C-ABI of the CILRS engine.
+//
+// The plan is the MI355X-side restatement of the graph the reference builds in
+// CILRS.__init__/forward (model/autonomous_drive.py:361-399): ResNet-34 trunk (torchvision
+// BasicBlock stacks [3,4,6,3]) -> 512-d feature; speed encoder 1->128->128; concat 640; four
+// command branches 640->256->256->3 (all evaluated, then gathered by `command`); speed head
+// 512->256->256->1.  Parameters live in ONE flat fp32 arena in nn.Module.parameters() order
+// (conv weights OHWI); gradients / Adam moments use the same layout, so clip + Adam are single
+// launches and data-parallel all-reduce works on contiguous ranges.
+#include "common.h"
+#include "../../include/cilrs_hip.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+namespace cilrs {
+
+static thread_local char g_err[1024] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+const char* last_error() { return g_err; }
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// Architecture: parameter arena layout
+// ------------------------------------------------------------------------------------------------
+struct ParamT { std::string name; size_t off, numel; int ndim; int shape[4]; };
+struct BnT { std::string prefix; int C; size_t gamma, beta, rm, rv; };
+struct ConvT { int cin, cout, k, stride, pad; size_t w; int bn; int group; };
+struct BlockT { int conv1, conv2, down; };
+struct LinT { int in, out; size_t w, b; };
+
+struct Arch {
+    std::vector<ParamT> params;
+    std::vector<BnT> bns;
+    std::vector<ConvT> convs;           // convs[0] = stem
+    std::vector<BlockT> blocks;
+    LinT se0, se3, br[4][3], sp0, sp3, sp5;
+    size_t arena_floats = 0, count = 0, bn_floats = 0;
+    size_t seg_begin[6], seg_end[6];    // 0 heads, 1 layer4, 2 layer3, 3 layer2, 4 layer1, 5 stem
+
+    size_t add_param(const std::string& name, int ndim, int s0, int s1 = 1, int s2 = 1,
+                     int s3 = 1) {
+        ParamT p;
+        p.name = name;
+        p.ndim = ndim;
+        p.shape[0] = s0; p.shape[1] = s1; p.shape[2] = s2; p.shape[3] = s3;
+        p.numel = (size_t)s0 * s1 * s2 * s3;
+        p.off = arena_floats;
+        arena_floats += (p.numel + 3) / 4 * 4;      // keep every tensor 16-byte aligned
+        count += p.numel;
+        params.push_back(p);
+        return p.off;
+    }
+    int add_bn(const std::string& prefix, int C) {
+        BnT b;
+        b.prefix = prefix;
+        b.C = C;
+        b.gamma = add_param(prefix + ".weight", 1, C);
+        b.beta = add_param(prefix + ".bias", 1, C);
+        b.rm = bn_floats;
+        b.rv = bn_floats + C;
+        bn_floats += 2 * (size_t)C;
+        bns.push_back(b);
+        return (int)bns.size() - 1;
+    }
+    int add_conv(const std::string& wname, const std::string& bnprefix, int cin, int cout, int k,
+                 int stride, int pad, int group) {
+        ConvT c;
+        c.cin = cin; c.cout = cout; c.k = k; c.stride = stride; c.pad = pad; c.group = group;
+        c.w = add_param(wname, 4, cout, cin, k, k);          // logical OIHW, stored OHWI
+        c.bn = add_bn(bnprefix, cout);
+        convs.push_back(c);
+        return (int)convs.size() - 1;
+    }
+    LinT add_lin(const std::string& prefix, int in, int out) {
+        LinT l;
+        l.in = in; l.out = out;
+        l.w = add_param(prefix + ".weight", 2, out, in);
+        l.b = add_param(prefix + ".bias", 1, out);
+        return l;
+    }
+
+    Arch() {
+        const size_t stem_begin = arena_floats;
+        add_conv("visual_encoder.0.weight", "visual_encoder.1", 3, 64, 7, 2, 3, 0);
+        size_t layer_begin[5];
+        const int nblk[4] = {3, 4, 6, 3};
+        const int width[4] = {64, 128, 256, 512};
+        int inpl = 64;
+        for (int L = 0; L < 4; ++L) {
+            layer_begin[L] = arena_floats;
+            for (int b = 0; b < nblk[L]; ++b) {
+                const std::string p =
+                    "visual_encoder." + std::to_string(4 + L) + "." + std::to_string(b);
+                const int stride = (b == 0 && L > 0) ? 2 : 1;
+                BlockT blk;
+                blk.conv1 = add_conv(p + ".conv1.weight", p + ".bn1", inpl, width[L], 3, stride,
+                                     1, L + 1);
+                blk.conv2 = add_conv(p + ".conv2.weight", p + ".bn2", width[L], width[L], 3, 1, 1,
+                                     L + 1);
+                blk.down = -1;
+                if (stride != 1 || inpl != width[L])
+                    blk.down = add_conv(p + ".downsample.0.weight", p + ".downsample.1", inpl,
+                                        width[L], 1, stride, 0, L + 1);
+                blocks.push_back(blk);
+                inpl = width[L];
+            }
+        }
+        layer_begin[4] = arena_floats;
+        se0 = add_lin("speed_encoder.0", 1, 128);
+        se3 = add_lin("speed_encoder.3", 128, 128);
+        for (int k = 0; k < 4; ++k) {
+            const std::string p = "control_branches." + std::to_string(k);
+            br[k][0] = add_lin(p + ".0", 640, 256);
+            br[k][1] = add_lin(p + ".3", 256, 256);
+            br[k][2] = add_lin(p + ".6", 256, 3);
+        }
+        sp0 = add_lin("speed_predictor.0", 512, 256);
+        sp3 = add_lin("speed_predictor.3", 256, 256);
+        sp5 = add_lin("speed_predictor.5", 256, 1);
+        seg_begin[0] = layer_begin[4]; seg_end[0] = arena_floats;
+        for (int L = 0; L < 4; ++L) {          // seg 1 = layer4 ... seg 4 = layer1
+            seg_begin[4 - L] = layer_begin[L];
+            seg_end[4 - L] = layer_begin[L + 1];
+        }
+        seg_begin[5] = stem_begin; seg_end[5] = layer_begin[0];
+    }
+};
+
+const Arch& arch() {
+    static const Arch a;
+    return a;
+}
+
+const char* kGroupName[5] = {"stem", "layer1", "layer2", "layer3", "layer4"};
+
+// ------------------------------------------------------------------------------------------------
+// Per-kernel timing
+// ------------------------------------------------------------------------------------------------
+struct ProfRec { int label; hipEvent_t e0, e1; double flops, bytes; };
+struct ProfAgg { long long calls = 0; double ms = 0, flops = 0, bytes = 0; };
+
+struct Prof {
+    bool on = false;
+    std::vector<std::string> labels;
+    std::map<std::string, int> index;
+    std::vector<ProfAgg> agg;
+    std::vector<ProfRec> pending;
+    std::vector<hipEvent_t> pool;
+
+    int label_id(const std::string& s) {
+        auto it = index.find(s);
+        if (it != index.end()) return it->second;
+        const int id = (int)labels.size();
+        labels.push_back(s);
+        agg.push_back(ProfAgg());
+        index[s] = id;
+        return id;
+    }
+    hipEvent_t get_event() {
+        if (!pool.empty()) {
+            hipEvent_t e = pool.back();
+            pool.pop_back();
+            return e;
+        }
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        return e;
+    }
+    int collect() {
+        for (auto& r : pending) {
+            CILRS_HIP(hipEventSynchronize(r.e1));
+            float ms = 0.f;
+            CILRS_HIP(hipEventElapsedTime(&ms, r.e0, r.e1));
+            ProfAgg& a = agg[r.label];
+            a.calls += 1; a.ms += ms; a.flops += r.flops; a.bytes += r.bytes;
+            pool.push_back(r.e0);
+            pool.push_back(r.e1);
+        }
+        pending.clear();
+        return 0;
+    }
+    ~Prof() {
+        for (auto& r : pending) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+        for (auto e : pool) (void)hipEventDestroy(e);
+    }
+};
+
+}  // namespace
+}  // namespace cilrs
+
+using namespace cilrs;
+
+// ------------------------------------------------------------------------------------------------
+// The plan
+// ------------------------------------------------------------------------------------------------
+struct ConvG { int H, W, Ho, Wo, M; size_t y, z, stats; };
+
+struct cilrs_net {
+    int B, H, W;
+    std::vector<ConvG> cg;                 // geometry + workspace offsets (floats) per conv
+    int H0, W0, H1, W1;                    // stem conv out, maxpool out
+    int featHW;
+    // workspace offsets (in floats unless noted)
+    size_t x4, w4, pool, argmax_b /*bytes offset*/, combined, s1, p1, p2, h1[4], h2[4], all_out;
+    size_t dcombined, ds1, dp1, dp2, dh1, dh2, d_all, speed_in, cmd_b /*bytes offset*/;
+    size_t G[4];                           // rotating gradient buffers (max activation size)
+    size_t gmax;
+    size_t bn_partial, bn_coef, slabs, slabs_floats, ksplit, ksplit_floats, status_b;
+    size_t ws_bytes;
+    bool trained_fwd = false;
+    float last_dropout = 0.f;
+    Prof prof;
+};
+
+namespace {
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Bump {
+    size_t off = 0;   // floats
+    size_t take(size_t floats) {
+        const size_t o = off;
+        off = align_up(off + floats, 64);
+        return o;
+    }
+};
+
+#define RUN(NET_, LBL_, FL_, BY_, ST_, CALL_)                                         \
+    do {                                                                              \
+        Prof& pr_ = (NET_)->prof;                                                     \
+        if (pr_.on) {                                                                 \
+            ProfRec r_;                                                               \
+            r_.label = pr_.label_id(LBL_);                                            \
+            r_.flops = (FL_); r_.bytes = (BY_);                                       \
+            r_.e0 = pr_.get_event(); r_.e1 = pr_.get_event();                         \
+            CILRS_CHECK(r_.e0 && r_.e1, "hipEventCreate failed");                     \
+            CILRS_HIP(hipEventRecord(r_.e0, (ST_)));                                  \
+            if (CALL_) return 1;                                                      \
+            CILRS_HIP(hipEventRecord(r_.e1, (ST_)));                                  \
+            pr_.pending.push_back(r_);                                                \
+        } else {                                                                      \
+            if (CALL_) return 1;                                                      \
+        }                                                                             \
+    } while (0)
+
+int conv_fwd(cilrs_net* net, const ConvT& c, const ConvG& g, const float* x, int x_cin,
+             const float* w, float* y, float* ws, hipStream_t s) {
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.w = w; a.y = y;
+    a.N = net->B; a.H = g.H; a.W = g.W; a.Cin = x_cin;
+    a.Ho = g.Ho; a.Wo = g.Wo; a.Cout = c.cout;
+    a.KH = a.KW = c.k; a.stride = c.stride; a.pad = c.pad; a.dil = 1;
+    a.x_ld = x_cin; a.y_ld = c.cout; a.w_mode = 0; a.w_cin = x_cin;
+    a.scratch = ws + net->ksplit; a.scratch_floats = net->ksplit_floats;
+    a.force_cfg = -1;
+    const double flops = 2.0 * g.M * c.cout * c.k * c.k * c.cin;
+    const double bytes = 4.0 * ((double)net->B * g.H * g.W * c.cin + (double)g.M * c.cout +
+                                (double)c.cout * c.k * c.k * c.cin);
+    RUN(net, std::string("conv_fwd.") + kGroupName[c.group], flops, bytes, s,
+        launch_conv_igemm(a, s));
+    return 0;
+}
+
+// dx[B,H,W,cin] (+= addend) from dy[B,Ho,Wo,cout]
+int conv_dgrad(cilrs_net* net, const ConvT& c, const ConvG& g, const float* dy, const float* w,
+               float* dx, const float* addend, float* ws, hipStream_t s) {
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = dy; a.w = w; a.y = dx; a.addend = addend;
+    a.N = net->B; a.H = g.Ho; a.W = g.Wo; a.Cin = c.cout;
+    a.Ho = g.H; a.Wo = g.W; a.Cout = c.cin;
+    a.KH = a.KW = c.k; a.stride = 1; a.pad = c.k - 1 - c.pad; a.dil = c.stride;
+    a.x_ld = c.cout; a.y_ld = c.cin; a.w_mode = 1; a.w_cin = c.cin;
+    a.scratch = ws + net->ksplit; a.scratch_floats = net->ksplit_floats;
+    a.force_cfg = -1;
+    const double flops = 2.0 * g.M * c.cout * c.k * c.k * c.cin;
+    const double bytes = 4.0 * ((double)net->B * g.H * g.W * c.cin + (double)g.M * c.cout +
+                                (double)c.cout * c.k * c.k * c.cin);
+    RUN(net, std::string("conv_dgrad.") + kGroupName[c.group], flops, bytes, s,
+        launch_conv_igemm(a, s));
+    return 0;
+}
+
+int conv_wgrad(cilrs_net* net, const ConvT& c, const ConvG& g, const float* x, int x_cin,
+               const float* dy, float* dw, float* ws, hipStream_t s) {
+    WgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.dy = dy; a.dw = dw; a.slabs = ws + net->slabs;
+    a.N = net->B; a.H = g.H; a.W = g.W; a.Cin = x_cin;
+    a.Ho = g.Ho; a.Wo = g.Wo; a.Cout = c.cout;
+    a.KH = a.KW = c.k; a.stride = c.stride; a.pad = c.pad;
+    a.x_ld = x_cin; a.dy_ld = c.cout; a.Cin_dst = c.cin; a.accumulate = 0;
+    CILRS_CHECK(wgrad_scratch_floats(a) <= net->slabs_floats, "wgrad scratch too small");
+    const double flops = 2.0 * g.M * c.cout * c.k * c.k * c.cin;
+    const double bytes = 4.0 * ((double)net->B * g.H * g.W * c.cin + (double)g.M * c.cout +
+                                (double)c.cout * c.k * c.k * c.cin);
+    RUN(net, std::string("conv_wgrad.") + kGroupName[c.group], flops, bytes, s,
+        launch_conv_wgrad(a, s));
+    return 0;
+}
+
+// wide linear layer on the matrix pipe: y[B][out] = relu?(x[B][in] W^T + b)
+int lin_fwd(cilrs_net* net, const LinT& l, const float* P, const float* x, int x_ld, float* y,
+            int y_ld, int relu, hipStream_t s) {
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.w = P + l.w; a.y = y; a.bias = P + l.b;
+    a.N = net->B; a.H = 1; a.W = 1; a.Cin = l.in; a.Ho = 1; a.Wo = 1; a.Cout = l.out;
+    a.KH = a.KW = 1; a.stride = 1; a.pad = 0; a.dil = 1;
+    a.x_ld = x_ld; a.y_ld = y_ld; a.w_mode = 0; a.w_cin = l.in; a.relu = relu;
+    a.force_cfg = -1;
+    RUN(net, "heads_fwd", 2.0 * net->B * l.in * l.out, 4.0 * l.in * l.out, s,
+        launch_conv_igemm(a, s));
+    return 0;
+}
+
+// dx[B][in] = (dy[B][out] W) [masked by act>0, scaled] [+ addend]
+int lin_dgrad(cilrs_net* net, const LinT& l, const float* P, const float* dy, int dy_ld,
+              float* dx, int dx_ld, const float* act, int act_ld, float act_scale,
+              const float* addend, hipStream_t s) {
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = dy; a.w = P + l.w; a.y = dx; a.addend = addend; a.mask = act; a.mask_ld = act_ld;
+    a.mask_scale = act_scale;
+    a.N = net->B; a.H = 1; a.W = 1; a.Cin = l.out; a.Ho = 1; a.Wo = 1; a.Cout = l.in;
+    a.KH = a.KW = 1; a.stride = 1; a.pad = 0; a.dil = 1;
+    a.x_ld = dy_ld; a.y_ld = dx_ld; a.w_mode = 1; a.w_cin = l.in;
+    a.force_cfg = -1;
+    RUN(net, "heads_bwd", 2.0 * net->B * l.in * l.out, 4.0 * l.in * l.out, s,
+        launch_conv_igemm(a, s));
+    return 0;
+}
+
+// dW[out][in] = dy^T x ; db = colsum(dy)
+int lin_wgrad(cilrs_net* net, const LinT& l, float* Gp, const float* x, int x_ld, const float* dy,
+              int dy_ld, float* ws, hipStream_t s) {
+    WgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.dy = dy; a.dw = Gp + l.w; a.slabs = ws + net->slabs;
+    a.N = net->B; a.H = 1; a.W = 1; a.Cin = l.in; a.Ho = 1; a.Wo = 1; a.Cout = l.out;
+    a.KH = a.KW = 1; a.stride = 1; a.pad = 0;
+    a.x_ld = x_ld; a.dy_ld = dy_ld; a.Cin_dst = l.in; a.accumulate = 0;
+    CILRS_CHECK(wgrad_scratch_floats(a) <= net->slabs_floats, "wgrad scratch too small (heads)");
+    RUN(net, "heads_bwd", 2.0 * net->B * l.in * l.out, 4.0 * l.in * l.out, s,
+        launch_conv_wgrad(a, s));
+    RUN(net, "heads_bwd", 0.0, 0.0, s, launch_colsum(dy, Gp + l.b, net->B, l.out, dy_ld, 0, s));
+    return 0;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// C-ABI: layout queries
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+int cilrs_version(void) { return 1; }
+const char* cilrs_last_error(void) { return last_error(); }
+int cilrs_num_params(void) { return (int)arch().params.size(); }
+int cilrs_num_bn(void) { return (int)arch().bns.size(); }
+size_t cilrs_param_arena_floats(void) { return arch().arena_floats; }
+size_t cilrs_param_count(void) { return arch().count; }
+size_t cilrs_bn_arena_floats(void) { return arch().bn_floats; }
+
+int cilrs_param_info(int i, char* name, int name_cap, size_t* offset, size_t* numel, int* ndim,
+                     int* shape4) {
+    const Arch& A = arch();
+    CILRS_CHECK(i >= 0 && i < (int)A.params.size(), "param index %d out of range", i);
+    const ParamT& p = A.params[i];
+    if (name && name_cap > 0) snprintf(name, name_cap, "%s", p.name.c_str());
+    if (offset) *offset = p.off;
+    if (numel) *numel = p.numel;
+    if (ndim) *ndim = p.ndim;
+    if (shape4) for (int k = 0; k < 4; ++k) shape4[k] = p.shape[k];
+    return 0;
+}
+
+int cilrs_bn_info(int j, char* prefix, int prefix_cap, int* channels, size_t* rm_offset,
+                  size_t* rv_offset) {
+    const Arch& A = arch();
+    CILRS_CHECK(j >= 0 && j < (int)A.bns.size(), "bn index %d out of range", j);
+    const BnT& b = A.bns[j];
+    if (prefix && prefix_cap > 0) snprintf(prefix, prefix_cap, "%s", b.prefix.c_str());
+    if (channels) *channels = b.C;
+    if (rm_offset) *rm_offset = b.rm;
+    if (rv_offset) *rv_offset = b.rv;
+    return 0;
+}
+
+int cilrs_segment_range(int seg, size_t* begin, size_t* end) {
+    CILRS_CHECK(seg >= 0 && seg < 6, "segment %d out of range", seg);
+    *begin = arch().seg_begin[seg];
+    *end = arch().seg_end[seg];
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// plan creation
+// ------------------------------------------------------------------------------------------------
+int cilrs_net_create(int batch, int height, int width, cilrs_net** out) {
+    CILRS_CHECK(out != nullptr, "cilrs_net_create: out is NULL");
+    CILRS_CHECK(batch >= 1 && height >= 32 && width >= 32, "cilrs_net_create: bad geometry %d %d %d",
+                batch, height, width);
+    const Arch& A = arch();
+    cilrs_net* n = new cilrs_net();
+    n->B = batch; n->H = height; n->W = width;
+    n->cg.resize(A.convs.size());
+    Bump bump;
+    const int B = batch;
+    n->x4 = bump.take((size_t)B * height * width * 4);
+    n->w4 = bump.take((size_t)64 * 49 * 4);
+
+    auto out_dim = [](int in, int k, int s, int p) { return (in + 2 * p - k) / s + 1; };
+    // stem
+    {
+        ConvG& g = n->cg[0];
+        g.H = height; g.W = width;
+        g.Ho = out_dim(height, 7, 2, 3); g.Wo = out_dim(width, 7, 2, 3);
+        g.M = B * g.Ho * g.Wo;
+        g.y = bump.take((size_t)g.M * 64);
+        g.z = bump.take((size_t)g.M * 64);
+        g.stats = bump.take(4 * 64);
+        n->H0 = g.Ho; n->W0 = g.Wo;
+        n->H1 = out_dim(g.Ho, 3, 2, 1); n->W1 = out_dim(g.Wo, 3, 2, 1);
+    }
+    size_t gmax = (size_t)n->cg[0].M * 64;
+    n->pool = bump.take((size_t)B * n->H1 * n->W1 * 64);
+    const size_t argmax_floats = ((size_t)B * n->H1 * n->W1 * 64 + 3) / 4;
+    n->argmax_b = bump.take(argmax_floats) * sizeof(float);
+    int h = n->H1, w = n->W1;
+    size_t slabs_max = 0, ksplit_max = 0;
+    auto track = [&](const ConvT& c, const ConvG& g, int x_cin) {
+        WgradArgs wa;
+        memset(&wa, 0, sizeof(wa));
+        wa.N = B; wa.H = g.H; wa.W = g.W; wa.Cin = x_cin; wa.Ho = g.Ho; wa.Wo = g.Wo;
+        wa.Cout = c.cout; wa.KH = wa.KW = c.k; wa.stride = c.stride; wa.pad = c.pad;
+        const size_t sf = wgrad_scratch_floats(wa);
+        if (sf > slabs_max) slabs_max = sf;
+        // split-K scratch: only worthwhile for the small-M layers
+        const size_t fwd = (size_t)g.M * c.cout, bwd = (size_t)B * g.H * g.W * c.cin;
+        const size_t big = fwd > bwd ? fwd : bwd;
+        if (big <= (size_t)6 * 1024 * 1024 && 8 * big > ksplit_max) ksplit_max = 8 * big;
+    };
+    track(A.convs[0], n->cg[0], 4);
+    for (const BlockT& blk : A.blocks) {
+        const ConvT& c1 = A.convs[blk.conv1];
+        ConvG& g1 = n->cg[blk.conv1];
+        g1.H = h; g1.W = w;
+        g1.Ho = out_dim(h, 3, c1.stride, 1); g1.Wo = out_dim(w, 3, c1.stride, 1);
+        g1.M = B * g1.Ho * g1.Wo;
+        g1.y = bump.take((size_t)g1.M * c1.cout);
+        g1.z = bump.take((size_t)g1.M * c1.cout);
+        g1.stats = bump.take(4 * c1.cout);
+        track(c1, g1, c1.cin);
+        const ConvT& c2 = A.convs[blk.conv2];
+        ConvG& g2 = n->cg[blk.conv2];
+        g2.H = g1.Ho; g2.W = g1.Wo; g2.Ho = g1.Ho; g2.Wo = g1.Wo; g2.M = g1.M;
+        g2.y = bump.take((size_t)g2.M * c2.cout);
+        g2.z = bump.take((size_t)g2.M * c2.cout);      // block output
+        g2.stats = bump.take(4 * c2.cout);
+        track(c2, g2, c2.cin);
+        if (blk.down >= 0) {
+            const ConvT& cd = A.convs[blk.down];
+            ConvG& gd = n->cg[blk.down];
+            gd.H = h; gd.W = w; gd.Ho = g1.Ho; gd.Wo = g1.Wo; gd.M = g1.M;
+            gd.y = bump.take((size_t)gd.M * cd.cout);
+            gd.z = bump.take((size_t)gd.M * cd.cout);
+            gd.stats = bump.take(4 * cd.cout);
+            track(cd, gd, cd.cin);
+        }
+        const size_t act = (size_t)B * h * w * c1.cin;
+        if (act > gmax) gmax = act;
+        if ((size_t)g1.M * c1.cout > gmax) gmax = (size_t)g1.M * c1.cout;
+        h = g1.Ho; w = g1.Wo;
+    }
+    n->featHW = h * w;
+    // heads
+    n->combined = bump.take((size_t)B * 640);
+    n->s1 = bump.take((size_t)B * 128);
+    n->p1 = bump.take((size_t)B * 256);
+    n->p2 = bump.take((size_t)B * 256);
+    for (int k = 0; k < 4; ++k) {
+        n->h1[k] = bump.take((size_t)B * 256);
+        n->h2[k] = bump.take((size_t)B * 256);
+    }
+    n->all_out = bump.take((size_t)4 * B * 4);
+    n->dcombined = bump.take((size_t)B * 640);
+    n->ds1 = bump.take((size_t)B * 128);
+    n->dp1 = bump.take((size_t)B * 256);
+    n->dp2 = bump.take((size_t)B * 256);
+    n->dh1 = bump.take((size_t)B * 256);
+    n->dh2 = bump.take((size_t)B * 256);
+    n->d_all = bump.take((size_t)4 * B * 4);
+    n->speed_in = bump.take((size_t)B);
+    n->cmd_b = bump.take((size_t)B * 2) * sizeof(float);
+    // the heads' wide linears also use the wgrad slabs
+    {
+        WgradArgs wa;
+        memset(&wa, 0, sizeof(wa));
+        wa.N = B; wa.H = wa.W = wa.Ho = wa.Wo = 1; wa.Cin = 640; wa.Cout = 256;
+        wa.KH = wa.KW = 1; wa.stride = 1;
+        const size_t sf = wgrad_scratch_floats(wa);
+        if (sf > slabs_max) slabs_max = sf;
+    }
+    n->gmax = gmax;
+    for (int i = 0; i < 4; ++i) n->G[i] = bump.take(gmax);
+    n->bn_partial = bump.take(bn_partial_floats(512));
+    n->bn_coef = bump.take(3 * 512);
+    n->slabs_floats = slabs_max;
+    n->slabs = bump.take(slabs_max);
+    n->ksplit_floats = ksplit_max;
+    n->ksplit = bump.take(ksplit_max > 0 ? ksplit_max : 4);
+    n->status_b = bump.take(64) * sizeof(float);
+    n->ws_bytes = bump.off * sizeof(float);
+    *out = n;
+    return 0;
+}
+
+void cilrs_net_destroy(cilrs_net* net) { delete net; }
+size_t cilrs_net_workspace_bytes(const cilrs_net* net) { return net ? net->ws_bytes : 0; }
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+static int forward_from_x4(cilrs_net* net, const cilrs_buffers* bufs, const float* speed,
+                           const int64_t* command, int train, float dropout_p, uint64_t seed,
+                           float* controls, float* pred_speed, hipStream_t s) {
+    const Arch& A = arch();
+    float* ws = reinterpret_cast<float*>(bufs->workspace);
+    const float* P = bufs->params;
+    float* R = bufs->bn_running;
+    const int B = net->B;
+    const float eps = 1e-5f, mom = 0.1f;
+
+    auto bn = [&](int ci, const float* residual, int relu) -> int {
+        const ConvT& c = A.convs[ci];
+        const ConvG& g = net->cg[ci];
+        const BnT& b = A.bns[c.bn];
+        const double bytes = 4.0 * g.M * c.cout * (residual ? 4.0 : 3.0);
+        if (train) {
+            RUN(net, std::string("bn_fwd.") + kGroupName[c.group], 0.0, bytes, s,
+                launch_bn_train_fwd(ws + g.y, g.M, c.cout, P + b.gamma, P + b.beta, R + b.rm,
+                                    R + b.rv, reinterpret_cast<long long*>(bufs->bn_nbt) + c.bn,
+                                    mom, eps, residual, relu, ws + g.stats, ws + net->bn_partial,
+                                    ws + g.z, s));
+        } else {
+            RUN(net, std::string("bn_fwd.") + kGroupName[c.group], 0.0, bytes, s,
+                launch_bn_eval_fwd(ws + g.y, g.M, c.cout, P + b.gamma, P + b.beta, R + b.rm,
+                                   R + b.rv, eps, residual, relu, ws + g.stats, ws + g.z, s));
+        }
+        return 0;
+    };
+
+    // ---- stem: conv7x7/s2 + BN + ReLU + maxpool3x3/s2 ----
+    RUN(net, "transform", 0.0, 0.0, s,
+        launch_pad_cin3_to_4(P + A.convs[0].w, ws + net->w4, 64 * 49, s));
+    if (conv_fwd(net, A.convs[0], net->cg[0], ws + net->x4, 4, ws + net->w4, ws + net->cg[0].y,
+                 ws, s)) return 1;
+    if (bn(0, nullptr, 1)) return 1;
+    unsigned char* argmax = reinterpret_cast<unsigned char*>(bufs->workspace) + net->argmax_b;
+    RUN(net, "maxpool", 0.0, 4.0 * net->cg[0].M * 64 * 1.25, s,
+        launch_maxpool_fwd(ws + net->cg[0].z, ws + net->pool, train ? argmax : nullptr, B,
+                           net->H0, net->W0, 64, s));
+
+    // ---- BasicBlocks ----
+    const float* cur = ws + net->pool;
+    for (const BlockT& blk : A.blocks) {
+        const ConvT& c1 = A.convs[blk.conv1];
+        const ConvT& c2 = A.convs[blk.conv2];
+        const ConvG& g1 = net->cg[blk.conv1];
+        const ConvG& g2 = net->cg[blk.conv2];
+        if (conv_fwd(net, c1, g1, cur, c1.cin, P + c1.w, ws + g1.y, ws, s)) return 1;
+        if (bn(blk.conv1, nullptr, 1)) return 1;
+        if (conv_fwd(net, c2, g2, ws + g1.z, c2.cin, P + c2.w, ws + g2.y, ws, s)) return 1;
+        const float* identity = cur;
+        if (blk.down >= 0) {
+            const ConvT& cd = A.convs[blk.down];
+            const ConvG& gd = net->cg[blk.down];
+            if (conv_fwd(net, cd, gd, cur, cd.cin, P + cd.w, ws + gd.y, ws, s)) return 1;
+            if (bn(blk.down, nullptr, 0)) return 1;
+            identity = ws + gd.z;
+        }
+        if (bn(blk.conv2, identity, 1)) return 1;
+        cur = ws + g2.z;
+    }
+
+    // ---- avgpool + flatten -> combined[:, 0:512] ----
+    RUN(net, "heads_fwd", 0.0, 0.0, s,
+        launch_avgpool_fwd(cur, ws + net->combined, B, net->featHW, 512, 640, s));
+
+    if (train) {   // backward needs the inputs of the heads
+        CILRS_HIP(hipMemcpyAsync(ws + net->speed_in, speed, (size_t)B * sizeof(float),
+                                 hipMemcpyDeviceToDevice, s));
+        CILRS_HIP(hipMemcpyAsync(reinterpret_cast<char*>(bufs->workspace) + net->cmd_b, command,
+                                 (size_t)B * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+    }
+    const float pdrop = train ? dropout_p : 0.f;
+    auto drop = [&](float* a, int cols, int ld, unsigned long long stream_id) -> int {
+        if (pdrop > 0.f)
+            RUN(net, "heads_fwd", 0.0, 0.0, s, launch_dropout(a, B, cols, ld, pdrop, seed,
+                                                              stream_id, s));
+        return 0;
+    };
+    // ---- speed encoder (autonomous_drive.py:371-374, 391) ----
+    RUN(net, "heads_fwd", 0.0, 0.0, s,
+        launch_linear_small_fwd(speed, P + A.se0.w, P + A.se0.b, ws + net->s1, B, 1, 128, 1, 128,
+                                1, s));
+    if (drop(ws + net->s1, 128, 128, 0)) return 1;
+    if (lin_fwd(net, A.se3, P, ws + net->s1, 128, ws + net->combined + 512, 640, 1, s)) return 1;
+    // ---- speed predictor (:383-387, 393) on the visual features ----
+    if (lin_fwd(net, A.sp0, P, ws + net->combined, 640, ws + net->p1, 256, 1, s)) return 1;
+    if (drop(ws + net->p1, 256, 256, 9)) return 1;
+    if (lin_fwd(net, A.sp3, P, ws + net->p1, 256, ws + net->p2, 256, 1, s)) return 1;
+    RUN(net, "heads_fwd", 0.0, 0.0, s,
+        launch_linear_small_fwd(ws + net->p2, P + A.sp5.w, P + A.sp5.b, pred_speed, B, 256, 1,
+                                256, 1, 0, s));
+    // ---- four branches, all evaluated (:394-396), then gathered by command (:397-398) ----
+    for (int k = 0; k < 4; ++k) {
+        if (lin_fwd(net, A.br[k][0], P, ws + net->combined, 640, ws + net->h1[k], 256, 1, s))
+            return 1;
+        if (drop(ws + net->h1[k], 256, 256, 1 + 2 * k)) return 1;
+        if (lin_fwd(net, A.br[k][1], P, ws + net->h1[k], 256, ws + net->h2[k], 256, 1, s))
+            return 1;
+        if (drop(ws + net->h2[k], 256, 256, 2 + 2 * k)) return 1;
+        RUN(net, "heads_fwd", 0.0, 0.0, s,
+            launch_linear_small_fwd(ws + net->h2[k], P + A.br[k][2].w, P + A.br[k][2].b,
+                                    ws + net->all_out + (size_t)k * B * 4, B, 256, 3, 256, 4, 0,
+                                    s));
+    }
+    int* status = reinterpret_cast<int*>(reinterpret_cast<char*>(bufs->workspace) + net->status_b);
+    RUN(net, "heads_fwd", 0.0, 0.0, s,
+        launch_branch_gather(ws + net->all_out, reinterpret_cast<const long long*>(command),
+                             controls, B, 4, status, s));
+    net->trained_fwd = train != 0;
+    net->last_dropout = pdrop;
+    return 0;
+}
+
+static int check_bufs(const cilrs_net* net, const cilrs_buffers* bufs, bool need_grads) {
+    CILRS_CHECK(net != nullptr && bufs != nullptr, "net / buffers missing");
+    CILRS_CHECK(bufs->params && bufs->bn_running && bufs->bn_nbt && bufs->workspace,
+                "cilrs_buffers has NULL members");
+    CILRS_CHECK(!need_grads || bufs->grads, "gradient arena missing");
+    CILRS_CHECK(((uintptr_t)bufs->params & 15) == 0 && ((uintptr_t)bufs->workspace & 255) == 0,
+                "params must be 16-byte and workspace 256-byte aligned");
+    return 0;
+}
+
+int cilrs_net_forward(cilrs_net* net, const cilrs_buffers* bufs, const float* image, long sn,
+                      long sc, long sh, long sw, const float* speed, const int64_t* command,
+                      int train, float dropout_p, uint64_t seed, float* controls,
+                      float* pred_speed, void* stream) {
+    if (check_bufs(net, bufs, false)) return 1;
+    CILRS_CHECK(image && speed && command && controls && pred_speed, "forward: NULL tensor");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    float* ws = reinterpret_cast<float*>(bufs->workspace);
+    CILRS_HIP(hipMemsetAsync(reinterpret_cast<char*>(bufs->workspace) + net->status_b, 0, 16, s));
+    RUN(net, "transform", 0.0, 0.0, s,
+        launch_nchw3_to_nhwc4(image, ws + net->x4, net->B, net->H, net->W, sn, sc, sh, sw, s));
+    return forward_from_x4(net, bufs, speed, command, train, dropout_p, seed, controls,
+                           pred_speed, s);
+}
+
+int cilrs_net_forward_u8(cilrs_net* net, const cilrs_buffers* bufs, const uint8_t* frames,
+                         const float* speed, const int64_t* command, float* controls,
+                         float* pred_speed, void* stream) {
+    if (check_bufs(net, bufs, false)) return 1;
+    CILRS_CHECK(frames && speed && command && controls && pred_speed, "forward_u8: NULL tensor");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    float* ws = reinterpret_cast<float*>(bufs->workspace);
+    CILRS_HIP(hipMemsetAsync(reinterpret_cast<char*>(bufs->workspace) + net->status_b, 0, 16, s));
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    RUN(net, "transform", 0.0, 0.0, s,
+        launch_u8hwc_to_nhwc4(frames, ws + net->x4, (size_t)net->B * net->H * net->W, mean, stdv,
+                              s));
+    return forward_from_x4(net, bufs, speed, command, 0, 0.f, 0, controls, pred_speed, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward
+// ------------------------------------------------------------------------------------------------
+static int backward_heads(cilrs_net* net, const cilrs_buffers* bufs, const float* dcontrols,
+                          const float* dps, const int64_t* command_unused, hipStream_t s);
+
+int cilrs_net_backward(cilrs_net* net, const cilrs_buffers* bufs, const float* dcontrols,
+                       const float* dpred_speed, int seg_begin, int seg_end, void* stream) {
+    if (check_bufs(net, bufs, true)) return 1;
+    CILRS_CHECK(net->trained_fwd, "backward needs a preceding train-mode forward on this plan");
+    CILRS_CHECK(0 <= seg_begin && seg_begin <= seg_end && seg_end <= 6, "bad segment range");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const Arch& A = arch();
+    float* ws = reinterpret_cast<float*>(bufs->workspace);
+    const float* P = bufs->params;
+    float* Gp = bufs->grads;
+    const int B = net->B;
+
+    for (int seg = seg_begin; seg < seg_end; ++seg) {
+        if (seg == 0) {
+            CILRS_CHECK(dcontrols && dpred_speed, "backward: output gradients missing");
+            if (backward_heads(net, bufs, dcontrols, dpred_speed, nullptr, s)) return 1;
+            // d visual -> avgpool backward -> grad of the last block's output, in G[3]
+            RUN(net, "heads_bwd", 0.0, 0.0, s,
+                launch_avgpool_bwd(ws + net->dcombined, ws + net->G[3], B, net->featHW, 512, 640,
+                                   s));
+            continue;
+        }
+        if (seg >= 1 && seg <= 4) {
+            const int layer = 5 - seg;                 // 4,3,2,1
+            // blocks of this layer, last to first; gradient of the block output is in G[3]
+            int first = 0;
+            const int nblk[4] = {3, 4, 6, 3};
+            for (int L = 1; L < layer; ++L) first += nblk[L - 1];
+            for (int bi = first + nblk[layer - 1] - 1; bi >= first; --bi) {
+                const BlockT& blk = A.blocks[bi];
+                const ConvT& c1 = A.convs[blk.conv1];
+                const ConvT& c2 = A.convs[blk.conv2];
+                const ConvG& g1 = net->cg[blk.conv1];
+                const ConvG& g2 = net->cg[blk.conv2];
+                const BnT& b1 = A.bns[c1.bn];
+                const BnT& b2 = A.bns[c2.bn];
+                // block input activation
+                const float* xin;
+                if (bi == 0) xin = ws + net->pool;
+                else xin = ws + net->cg[A.blocks[bi - 1].conv2].z;
+                float* Gd = ws + net->G[3];
+                float* Ga = ws + net->G[0];
+                float* Gb = ws + net->G[1];
+                float* Gc = ws + net->G[2];
+                const std::string grp = kGroupName[c1.group];
+                // 1. out = relu(bn2(y2) + identity): masked grad -> Gb, dy2 -> Ga
+                RUN(net, "bn_bwd." + grp, 0.0, 4.0 * g2.M * c2.cout * 8.0, s,
+                    launch_bn_bwd(Gd, ws + g2.z, ws + g2.y, g2.M, c2.cout, P + b2.gamma,
+                                  ws + g2.stats, 1, Gp + b2.gamma, Gp + b2.beta, 0,
+                                  ws + net->bn_coef, ws + net->bn_partial, Ga, Gb, s));
+                // 2./3. conv2: dW2, da -> Gc
+                if (conv_wgrad(net, c2, g2, ws + g1.z, c2.cin, Ga, Gp + c2.w, ws, s)) return 1;
+                if (conv_dgrad(net, c2, g2, Ga, P + c2.w, Gc, nullptr, ws, s)) return 1;
+                // 4. a = relu(bn1(y1)): dy1 -> Ga
+                RUN(net, "bn_bwd." + grp, 0.0, 4.0 * g1.M * c1.cout * 7.0, s,
+                    launch_bn_bwd(Gc, ws + g1.z, ws + g1.y, g1.M, c1.cout, P + b1.gamma,
+                                  ws + g1.stats, 1, Gp + b1.gamma, Gp + b1.beta, 0,
+                                  ws + net->bn_coef, ws + net->bn_partial, Ga, nullptr, s));
+                // 5. dW1
+                if (conv_wgrad(net, c1, g1, xin, c1.cin, Ga, Gp + c1.w, ws, s)) return 1;
+                if (blk.down < 0) {
+                    // 6. dx = dgrad(conv1) + identity grad (Gb) -> Gd
+                    if (conv_dgrad(net, c1, g1, Ga, P + c1.w, Gd, Gb, ws, s)) return 1;
+                } else {
+                    const ConvT& cd = A.convs[blk.down];
+                    const ConvG& gd = net->cg[blk.down];
+                    const BnT& bd = A.bns[cd.bn];
+                    if (conv_dgrad(net, c1, g1, Ga, P + c1.w, Gd, nullptr, ws, s)) return 1;
+                    // 7. identity = bn_d(conv_d(x)) (no ReLU): dy_d -> Gc
+                    RUN(net, "bn_bwd." + grp, 0.0, 4.0 * gd.M * cd.cout * 6.0, s,
+                        launch_bn_bwd(Gb, nullptr, ws + gd.y, gd.M, cd.cout, P + bd.gamma,
+                                      ws + gd.stats, 0, Gp + bd.gamma, Gp + bd.beta, 0,
+                                      ws + net->bn_coef, ws + net->bn_partial, Gc, nullptr, s));
+                    if (conv_wgrad(net, cd, gd, xin, cd.cin, Gc, Gp + cd.w, ws, s)) return 1;
+                    // 8. dx += dgrad(conv_d)
+                    if (conv_dgrad(net, cd, gd, Gc, P + cd.w, Gd, Gd, ws, s)) return 1;
+                }
+            }
+            continue;
+        }
+        // seg == 5: stem.  G[3] holds d(maxpool output)
+        {
+            const ConvT& c0 = A.convs[0];
+            const ConvG& g0 = net->cg[0];
+            const BnT& b0 = A.bns[c0.bn];
+            const unsigned char* argmax =
+                reinterpret_cast<const unsigned char*>(bufs->workspace) + net->argmax_b;
+            RUN(net, "maxpool", 0.0, 4.0 * g0.M * 64 * 1.5, s,
+                launch_maxpool_bwd(ws + net->G[3], argmax, ws + net->G[0], B, net->H0, net->W0,
+                                   64, s));
+            RUN(net, "bn_bwd.stem", 0.0, 4.0 * g0.M * 64 * 7.0, s,
+                launch_bn_bwd(ws + net->G[0], ws + g0.z, ws + g0.y, g0.M, 64, P + b0.gamma,
+                              ws + g0.stats, 1, Gp + b0.gamma, Gp + b0.beta, 0, ws + net->bn_coef,
+                              ws + net->bn_partial, ws + net->G[1], nullptr, s));
+            if (conv_wgrad(net, c0, g0, ws + net->x4, 4, ws + net->G[1], Gp + c0.w, ws, s))
+                return 1;
+        }
+    }
+    return 0;
+}
+
+static int backward_heads(cilrs_net* net, const cilrs_buffers* bufs, const float* dcontrols,
+                          const float* dps, const int64_t*, hipStream_t s) {
+    const Arch& A = arch();
+    float* ws = reinterpret_cast<float*>(bufs->workspace);
+    const float* P = bufs->params;
+    float* Gp = bufs->grads;
+    const int B = net->B;
+    const float dscale = net->last_dropout > 0.f ? 1.0f / (1.0f - net->last_dropout) : 1.0f;
+    const long long* cmd = reinterpret_cast<const long long*>(
+        reinterpret_cast<const char*>(bufs->workspace) + net->cmd_b);
+    float* dcomb = ws + net->dcombined;
+
+    // ---- branches: only the commanded branch of each frame receives gradient (gather) ----
+    RUN(net, "heads_bwd", 0.0, 0.0, s, launch_branch_scatter(dcontrols, cmd, ws + net->d_all, B, 4, s));
+    for (int k = 0; k < 4; ++k) {
+        const float* d_ok = ws + net->d_all + (size_t)k * B * 4;
+        const LinT& l2 = A.br[k][2];
+        RUN(net, "heads_bwd", 0.0, 0.0, s,
+            launch_linear_small_bwd(d_ok, ws + net->h2[k], P + l2.w, ws + net->h2[k], dscale,
+                                    ws + net->dh2, Gp + l2.w, Gp + l2.b, B, 256, 3, 4, 256, 256,
+                                    256, 0, s));
+        if (lin_wgrad(net, A.br[k][1], Gp, ws + net->h1[k], 256, ws + net->dh2, 256, ws, s))
+            return 1;
+        if (lin_dgrad(net, A.br[k][1], P, ws + net->dh2, 256, ws + net->dh1, 256, ws + net->h1[k],
+                      256, dscale, nullptr, s)) return 1;
+        if (lin_wgrad(net, A.br[k][0], Gp, ws + net->combined, 640, ws + net->dh1, 256, ws, s))
+            return 1;
+        if (lin_dgrad(net, A.br[k][0], P, ws + net->dh1, 256, dcomb, 640, nullptr, 0, 1.f,
+                      k > 0 ? dcomb : nullptr, s)) return 1;
+    }
+    // ---- speed predictor (reads the visual half of `combined`) ----
+    RUN(net, "heads_bwd", 0.0, 0.0, s,
+        launch_linear_small_bwd(dps, ws + net->p2, P + A.sp5.w, ws + net->p2, 1.0f, ws + net->dp2,
+                                Gp + A.sp5.w, Gp + A.sp5.b, B, 256, 1, 1, 256, 256, 256, 0, s));
+    if (lin_wgrad(net, A.sp3, Gp, ws + net->p1, 256, ws + net->dp2, 256, ws, s)) return 1;
+    if (lin_dgrad(net, A.sp3, P, ws + net->dp2, 256, ws + net->dp1, 256, ws + net->p1, 256,
+                  dscale, nullptr, s)) return 1;
+    if (lin_wgrad(net, A.sp0, Gp, ws + net->combined, 640, ws + net->dp1, 256, ws, s)) return 1;
+    if (lin_dgrad(net, A.sp0, P, ws + net->dp1, 256, dcomb, 640, nullptr, 0, 1.f, dcomb, s))
+        return 1;
+    // ---- speed encoder (the speed half of `combined`) ----
+    RUN(net, "heads_bwd", 0.0, 0.0, s,
+        launch_relu_mask(dcomb + 512, ws + net->combined + 512, B, 128, 640, 640, 1.0f, s));
+    if (lin_wgrad(net, A.se3, Gp, ws + net->s1, 128, dcomb + 512, 640, ws, s)) return 1;
+    if (lin_dgrad(net, A.se3, P, dcomb + 512, 640, ws + net->ds1, 128, ws + net->s1, 128, dscale,
+                  nullptr, s)) return 1;
+    RUN(net, "heads_bwd", 0.0, 0.0, s,
+        launch_linear_small_bwd(ws + net->ds1, ws + net->speed_in, P + A.se0.w, nullptr, 1.0f,
+                                nullptr, Gp + A.se0.w, Gp + A.se0.b, B, 1, 128, 128, 1, 1, 1, 0,
+                                s));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// loss / optimiser / profiling
+// ------------------------------------------------------------------------------------------------
+int cilrs_loss_fwd_bwd(const float* controls, const float* target_controls,
+                       const float* pred_speed, const float* target_speed, int batch, int kind,
+                       const float* weights4_host, float grad_scale, float* dcontrols,
+                       float* dpred_speed, float* loss_out, void* stream) {
+    CILRS_CHECK(controls && target_controls && pred_speed && target_speed && weights4_host &&
+                    loss_out, "loss: NULL argument");
+    CILRS_CHECK(batch >= 1, "loss: batch must be >= 1");
+    return launch_loss(controls, target_controls, pred_speed, target_speed, batch, kind,
+                       weights4_host, grad_scale, dcontrols, dpred_speed, loss_out,
+                       reinterpret_cast<hipStream_t>(stream));
+}
+
+size_t cilrs_sqnorm_scratch_bytes(void) { return sqnorm_scratch_bytes(); }
+
+int cilrs_grad_sqnorm(const float* grads, size_t n, float max_norm, void* scratch, float* out2,
+                      void* stream) {
+    CILRS_CHECK(grads && scratch && out2, "grad_sqnorm: NULL argument");
+    return launch_grad_sqnorm(grads, n, max_norm, reinterpret_cast<double*>(scratch), out2,
+                              reinterpret_cast<hipStream_t>(stream));
+}
+
+int cilrs_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                    size_t n, double lr, double beta1, double beta2, double eps,
+                    double weight_decay, int64_t step, const float* clip_out2, float grad_scale,
+                    void* stream) {
+    CILRS_CHECK(params && grads && exp_avg && exp_avg_sq, "adam: NULL argument");
+    return launch_adam(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay,
+                       (long long)step, clip_out2, grad_scale,
+                       reinterpret_cast<hipStream_t>(stream));
+}
+
+int cilrs_scale(float* x, size_t n, const float* clip_out2, float c, void* stream) {
+    CILRS_CHECK(x != nullptr, "scale: NULL argument");
+    return launch_scale(x, n, clip_out2, c, reinterpret_cast<hipStream_t>(stream));
+}
+
+int cilrs_net_profile_enable(cilrs_net* net, int on) {
+    CILRS_CHECK(net != nullptr, "profile: net is NULL");
+    net->prof.on = on != 0;
+    return 0;
+}
+int cilrs_net_profile_collect(cilrs_net* net) {
+    CILRS_CHECK(net != nullptr, "profile: net is NULL");
+    return net->prof.collect();
+}
+int cilrs_net_profile_count(const cilrs_net* net) { return net ? (int)net->prof.labels.size() : 0; }
+int cilrs_net_profile_entry(const cilrs_net* net, int i, char* label, int label_cap,
+                            long long* calls, double* total_ms, double* total_flops,
+                            double* total_bytes) {
+    CILRS_CHECK(net && i >= 0 && i < (int)net->prof.labels.size(), "profile: bad index");
+    if (label && label_cap > 0) snprintf(label, label_cap, "%s", net->prof.labels[i].c_str());
+    const ProfAgg& a = net->prof.agg[i];
+    if (calls) *calls = a.calls;
+    if (total_ms) *total_ms = a.ms;
+    if (total_flops) *total_flops = a.flops;
+    if (total_bytes) *total_bytes = a.bytes;
+    return 0;
+}
+int cilrs_net_profile_reset(cilrs_net* net) {
+    CILRS_CHECK(net != nullptr, "profile: net is NULL");
+    if (net->prof.collect()) return 1;
+    for (auto& a : net->prof.agg) a = ProfAgg();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// op-level entry points (unit parity tests)
+// ------------------------------------------------------------------------------------------------
+int cilrs_conv2d_fwd(const float* x, const float* w, float* y, int N, int H, int W, int Cin,
+                     int Cout, int KH, int KW, int stride, int pad, int force_cfg,
+                     int force_splitk, float* scratch, size_t scratch_floats, void* stream) {
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.w = w; a.y = y;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin;
+    a.Ho = (H + 2 * pad - KH) / stride + 1; a.Wo = (W + 2 * pad - KW) / stride + 1; a.Cout = Cout;
+    a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.dil = 1;
+    a.x_ld = Cin; a.y_ld = Cout; a.w_mode = 0; a.w_cin = Cin;
+    a.scratch = scratch; a.scratch_floats = scratch_floats;
+    a.force_cfg = force_cfg; a.force_splitk = force_splitk;
+    return launch_conv_igemm(a, reinterpret_cast<hipStream_t>(stream));
+}
+
+int cilrs_conv2d_dgrad(const float* dy, const float* w, float* dx, const float* addend, int N,
+                       int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                       int force_cfg, int force_splitk, float* scratch, size_t scratch_floats,
+                       void* stream) {
+    CILRS_CHECK(KH == KW, "dgrad: square kernels only");
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+    a.x = dy; a.w = w; a.y = dx; a.addend = addend;
+    a.N = N; a.H = Ho; a.W = Wo; a.Cin = Cout;
+    a.Ho = H; a.Wo = W; a.Cout = Cin;
+    a.KH = KH; a.KW = KW; a.stride = 1; a.pad = KH - 1 - pad; a.dil = stride;
+    a.x_ld = Cout; a.y_ld = Cin; a.w_mode = 1; a.w_cin = Cin;
+    a.scratch = scratch; a.scratch_floats = scratch_floats;
+    a.force_cfg = force_cfg; a.force_splitk = force_splitk;
+    return launch_conv_igemm(a, reinterpret_cast<hipStream_t>(stream));
+}
+
+static WgradArgs make_wgrad(const float* x, const float* dy, float* dw, float* scratch, int N,
+                            int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                            int Cin_dst) {
+    WgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.dy = dy; a.dw = dw; a.slabs = scratch;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin;
+    a.Ho = (H + 2 * pad - KH) / stride + 1; a.Wo = (W + 2 * pad - KW) / stride + 1; a.Cout = Cout;
+    a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
+    a.x_ld = Cin; a.dy_ld = Cout; a.Cin_dst = Cin_dst; a.accumulate = 0;
+    return a;
+}
+
+size_t cilrs_conv2d_wgrad_scratch_floats(int N, int H, int W, int Cin, int Cout, int KH, int KW,
+                                         int stride, int pad) {
+    return wgrad_scratch_floats(
+        make_wgrad(nullptr, nullptr, nullptr, nullptr, N, H, W, Cin, Cout, KH, KW, stride, pad, Cin));
+}
+
+int cilrs_conv2d_wgrad(const float* x, const float* dy, float* dw, float* scratch, int N, int H,
+                       int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                       int Cin_dst, void* stream) {
+    return launch_conv_wgrad(
+        make_wgrad(x, dy, dw, scratch, N, H, W, Cin, Cout, KH, KW, stride, pad, Cin_dst),
+        reinterpret_cast<hipStream_t>(stream));
+}
+
+size_t cilrs_bn_partial_floats(int C) { return bn_partial_floats(C); }
+
+int cilrs_bn_train_fwd(const float* y, int M, int C, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, int64_t* nbt, float momentum,
+                       float eps, const float* residual, int relu, float* stats, float* partial,
+                       float* z, void* stream) {
+    return launch_bn_train_fwd(y, M, C, gamma, beta, running_mean, running_var,
+                               reinterpret_cast<long long*>(nbt), momentum, eps, residual, relu,
+                               stats, partial, z, reinterpret_cast<hipStream_t>(stream));
+}
+int cilrs_bn_eval_fwd(const float* y, int M, int C, const float* gamma, const float* beta,
+                      const float* running_mean, const float* running_var, float eps,
+                      const float* residual, int relu, float* stats, float* z, void* stream) {
+    return launch_bn_eval_fwd(y, M, C, gamma, beta, running_mean, running_var, eps, residual,
+                              relu, stats, z, reinterpret_cast<hipStream_t>(stream));
+}
+int cilrs_bn_bwd(const float* dz, const float* z, const float* y, int M, int C,
+                 const float* gamma, const float* stats, int relu, float* dgamma, float* dbeta,
+                 float* coef3c, float* partial, float* dy, float* g_out, void* stream) {
+    return launch_bn_bwd(dz, z, y, M, C, gamma, stats, relu, dgamma, dbeta, 0, coef3c, partial, dy,
+                         g_out, reinterpret_cast<hipStream_t>(stream));
+}
+int cilrs_maxpool_fwd(const float* x, float* out, uint8_t* argmax, int N, int H, int W, int C,
+                      void* stream) {
+    return launch_maxpool_fwd(x, out, argmax, N, H, W, C, reinterpret_cast<hipStream_t>(stream));
+}
+int cilrs_maxpool_bwd(const float* dout, const uint8_t* argmax, float* dx, int N, int H, int W,
+                      int C, void* stream) {
+    return launch_maxpool_bwd(dout, argmax, dx, N, H, W, C, reinterpret_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,166 @@
+/* C-ABI of libcilrs_hip.so -- the MI355X (gfx950) engine behind the CILRS operator boundary.
+ *
+ * The reference has no FFI: its boundary for this path is the torch.nn.Module `CILRS`
+ * (model/autonomous_drive.py:361-399 == notebook/notebook.ipynb:440-477), its loss
+ * (notebook/notebook.ipynb:504-527) and torch.optim.Adam + clip_grad_norm_
+ * (notebook/notebook.ipynb:533-534, 553-555).  Each entry point below names the reference
+ * interface it replaces.  The Python mirror of that nn.Module (cilrs_mi355.CILRS) binds these
+ * symbols with ctypes -- see INTEGRATION.md for the stub a reference maintainer would add.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller (PyTorch-ROCm's allocator) and only
+ *    borrowed for the call, except `out_*` scalars explicitly marked host;
+ *  - `stream` is a hipStream_t; every function only ENQUEUES work and never synchronises
+ *    (cilrs_net_profile_collect excepted);
+ *  - return value 0 = ok; non-zero = error, text in cilrs_last_error() (thread-local);
+ *  - activations are NHWC fp32, conv weights OHWI fp32 (torch channels_last memory), all
+ *    arithmetic fp32 (exact-f32 MFMA), reductions deterministic.
+ */
+#ifndef CILRS_HIP_H
+#define CILRS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cilrs_net cilrs_net;
+
+int cilrs_version(void);
+const char* cilrs_last_error(void);
+
+/* ---- parameter / buffer arena layout (replaces nn.Module.parameters()/state_dict() order,
+ *      autonomous_drive.py:497 strict key contract) ----------------------- */
+/* number of parameter tensors (142), of BatchNorm layers (36) */
+int cilrs_num_params(void);
+int cilrs_num_bn(void);
+/* floats in the parameter arena (each tensor 16-byte aligned; >= 22,421,453) and exact count */
+size_t cilrs_param_arena_floats(void);
+size_t cilrs_param_count(void);
+/* tensor i: state_dict name, float offset into the arena, numel, logical torch shape (ndim<=4).
+ * Conv weights are stored OHWI at that offset (logical OIHW shape reported). */
+int cilrs_param_info(int i, char* name, int name_cap, size_t* offset, size_t* numel, int* ndim,
+                     int* shape4);
+/* BatchNorm j: module prefix ("visual_encoder.1", ...), channels, float offsets of running_mean /
+ * running_var inside the BN buffer arena; num_batches_tracked lives at int64 index j */
+int cilrs_bn_info(int j, char* prefix, int prefix_cap, int* channels, size_t* rm_offset,
+                  size_t* rv_offset);
+size_t cilrs_bn_arena_floats(void);
+
+/* ---- network plan ----------------------------------------------------------------------------- */
+typedef struct {
+    float* params;          /* parameter arena                               */
+    float* grads;           /* gradient arena, same layout (may be NULL for inference) */
+    float* bn_running;      /* BN running_mean / running_var arena            */
+    int64_t* bn_nbt;        /* [36] num_batches_tracked                       */
+    void* workspace;        /* cilrs_net_workspace_bytes() bytes              */
+} cilrs_buffers;
+
+/* plan for a fixed batch / frame size (reference: B x 3 x 88 x 200) */
+int cilrs_net_create(int batch, int height, int width, cilrs_net** out);
+void cilrs_net_destroy(cilrs_net* net);
+size_t cilrs_net_workspace_bytes(const cilrs_net* net);
+
+/* CILRS.forward(image, speed, command) -> (controls[B,3], pred_speed[B])
+ * (autonomous_drive.py:389-399).  image: f32 logical NCHW [B,3,H,W] with element strides
+ * (sn,sc,sh,sw); speed f32 [B]; command int64 [B] in {0..3}.
+ * train != 0: BatchNorm uses batch statistics and updates running stats (model.train());
+ * train == 0: running statistics (model.eval()).  dropout_p applies only when train != 0. */
+int cilrs_net_forward(cilrs_net* net, const cilrs_buffers* bufs, const float* image, long sn,
+                      long sc, long sh, long sw, const float* speed, const int64_t* command,
+                      int train, float dropout_p, uint64_t seed, float* controls,
+                      float* pred_speed, void* stream);
+
+/* Same, fed with uint8 RGB HWC frames [B,H,W,3]: fuses preprocess_image's /255, HWC->CHW and
+ * Normalize(mean,std) (autonomous_drive.py:897-902; the cv2.resize is the caller's). */
+int cilrs_net_forward_u8(cilrs_net* net, const cilrs_buffers* bufs, const uint8_t* frames,
+                         const float* speed, const int64_t* command, float* controls,
+                         float* pred_speed, void* stream);
+
+/* CILRSLoss.forward + its gradient (notebook/notebook.ipynb:514-527).
+ * kind 1: w0*L1(steer)+w1*L1(throttle)+w2*L1(brake)+w3*MSE(speed)     (executed config B)
+ * kind 0: MSE(controls[B,3]) + w3*MSE(speed)                            (documented config A)
+ * loss_out[6] (device) = total, control, steer, throttle, brake, speed.
+ * dcontrols[B,3] / dpred_speed[B] = d total / d prediction, times grad_scale. */
+int cilrs_loss_fwd_bwd(const float* controls, const float* target_controls,
+                       const float* pred_speed, const float* target_speed, int batch, int kind,
+                       const float* weights4_host, float grad_scale, float* dcontrols,
+                       float* dpred_speed, float* loss_out, void* stream);
+
+/* loss.backward() (notebook/notebook.ipynb:552) for the graph recorded by the last train-mode
+ * cilrs_net_forward: writes (overwrites) every parameter gradient of the segments
+ * [seg_begin, seg_end) into bufs->grads.  Segments, in execution order:
+ * 0 heads, 1 layer4, 2 layer3, 3 layer2, 4 layer1, 5 stem  (so data-parallel callers can
+ * all-reduce a finished segment's gradient range while the next one runs). */
+int cilrs_net_backward(cilrs_net* net, const cilrs_buffers* bufs, const float* dcontrols,
+                       const float* dpred_speed, int seg_begin, int seg_end, void* stream);
+/* float range [begin,end) of the gradient arena that segment `seg` produces */
+int cilrs_segment_range(int seg, size_t* begin, size_t* end);
+
+/* torch.nn.utils.clip_grad_norm_ (notebook/notebook.ipynb:553-554): out[0] = total L2 norm,
+ * out[1] = min(1, max_norm/(norm+1e-6)) (1 when max_norm <= 0); device results, no sync.
+ * scratch: cilrs_sqnorm_scratch_bytes() bytes. */
+size_t cilrs_sqnorm_scratch_bytes(void);
+int cilrs_grad_sqnorm(const float* grads, size_t n, float max_norm, void* scratch, float* out2,
+                      void* stream);
+
+/* torch.optim.Adam.step() with coupled L2 weight decay (notebook/notebook.ipynb:533-534, 555)
+ * over a flat arena; `step` is the 1-based step count; clip_out2 (may be NULL) is the device
+ * result of cilrs_grad_sqnorm whose [1] scales the gradients; grad_scale multiplies them too
+ * (1/world_size for data parallel sums). */
+int cilrs_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                    size_t n, double lr, double beta1, double beta2, double eps,
+                    double weight_decay, int64_t step, const float* clip_out2, float grad_scale,
+                    void* stream);
+int cilrs_scale(float* x, size_t n, const float* clip_out2, float c, void* stream);
+
+/* ---- per-kernel timing (hipEvents on the launch stream; feeds bench.py's roofline) ---------- */
+int cilrs_net_profile_enable(cilrs_net* net, int on);
+/* synchronises the recorded events and folds them into the per-label table */
+int cilrs_net_profile_collect(cilrs_net* net);
+int cilrs_net_profile_count(const cilrs_net* net);
+int cilrs_net_profile_entry(const cilrs_net* net, int i, char* label, int label_cap,
+                            long long* calls, double* total_ms, double* total_flops,
+                            double* total_bytes);
+int cilrs_net_profile_reset(cilrs_net* net);
+
+/* ---- op-level entry points (unit parity tests; same kernels the plan launches) -------------- */
+/* nn.Conv2d forward, NHWC x [N,H,W,Cin] (Cin % 4 == 0), OHWI w, y [N,Ho,Wo,Cout] (Cout % 64 == 0)
+ * force_cfg: -1 auto, 0/1/2 tile config; force_splitk: 0 auto; scratch may be NULL */
+int cilrs_conv2d_fwd(const float* x, const float* w, float* y, int N, int H, int W, int Cin,
+                     int Cout, int KH, int KW, int stride, int pad, int force_cfg,
+                     int force_splitk, float* scratch, size_t scratch_floats, void* stream);
+/* d(loss)/dx of the same conv: dy [N,Ho,Wo,Cout] -> dx [N,H,W,Cin] (+ addend if non-NULL) */
+int cilrs_conv2d_dgrad(const float* dy, const float* w, float* dx, const float* addend, int N,
+                       int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                       int force_cfg, int force_splitk, float* scratch, size_t scratch_floats,
+                       void* stream);
+/* d(loss)/dw (OHWI, Cin_dst channels kept); scratch from cilrs_conv2d_wgrad_scratch_floats */
+size_t cilrs_conv2d_wgrad_scratch_floats(int N, int H, int W, int Cin, int Cout, int KH, int KW,
+                                         int stride, int pad);
+int cilrs_conv2d_wgrad(const float* x, const float* dy, float* dw, float* scratch, int N, int H,
+                       int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                       int Cin_dst, void* stream);
+/* nn.BatchNorm2d training forward (+ optional residual add, ReLU); stats: 4*C floats out */
+size_t cilrs_bn_partial_floats(int C);
+int cilrs_bn_train_fwd(const float* y, int M, int C, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, int64_t* nbt, float momentum,
+                       float eps, const float* residual, int relu, float* stats, float* partial,
+                       float* z, void* stream);
+int cilrs_bn_eval_fwd(const float* y, int M, int C, const float* gamma, const float* beta,
+                      const float* running_mean, const float* running_var, float eps,
+                      const float* residual, int relu, float* stats, float* z, void* stream);
+int cilrs_bn_bwd(const float* dz, const float* z, const float* y, int M, int C,
+                 const float* gamma, const float* stats, int relu, float* dgamma, float* dbeta,
+                 float* coef3c, float* partial, float* dy, float* g_out, void* stream);
+int cilrs_maxpool_fwd(const float* x, float* out, uint8_t* argmax, int N, int H, int W, int C,
+                      void* stream);
+int cilrs_maxpool_bwd(const float* dout, const uint8_t* argmax, float* dx, int N, int H, int W,
+                      int C, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CILRS_HIP_H */

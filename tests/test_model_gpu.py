@@ -1,0 +1,256 @@
+"""Model-level parity of the HIP engine behind the CILRS boundary: against the committed golden
+fixtures (generated from the reference's own source, oracle/make_golden.py) and against the CPU
+oracle run live on the same seeded inputs.
+
+Tolerances (BASELINE.json north_star: "within 1e-4 fp32 on identical batches"):
+  outputs         abs 1e-4
+  losses          abs 1e-4
+  gradients       per-tensor max-abs error <= 2e-4 * max(1, max|g|)
+  params after k Adam steps   abs 5e-6 + summation noise (lr <= 2e-4 bounds each update)
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cilrs_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL_OUT = 1e-4
+
+
+def make_model(seed=0, dropout=0.0):
+    from cilrs_mi355 import CILRS
+    m = CILRS(num_commands=4, dropout=dropout)
+    m.load_state_dict(O.portable_state_dict(m.state_dict(), seed), strict=True)
+    return m.cuda()
+
+
+def to_dev(*ts):
+    return [t.cuda() for t in ts]
+
+
+def test_forward_eval_golden_and_oracle(golden_dir):
+    g = np.load(os.path.join(golden_dir, "forward_eval_b4.npz"))
+    m = make_model().eval()
+    img, spd, _, _, _ = O.synthetic_batch(4, seed=int(g["seed"]))
+    cmd = torch.from_numpy(g["command"])
+    with torch.no_grad():
+        c, s = m(*to_dev(img, spd, cmd))
+    assert isinstance(c, torch.Tensor) and c.shape == (4, 3) and s.shape == (4,)
+    assert np.abs(c.cpu().numpy() - g["controls"]).max() <= TOL_OUT
+    assert np.abs(s.cpu().numpy() - g["pred_speed"]).max() <= TOL_OUT
+    # live oracle on another batch size / seed, all four commands present
+    orc = O.build_oracle(0).eval()
+    img, spd, cmd, _, _ = O.synthetic_batch(6, seed=77)
+    with torch.no_grad():
+        oc, os_ = orc(img, spd, cmd)
+        c, s = m(*to_dev(img, spd, cmd))
+    assert (c.cpu() - oc).abs().max() <= TOL_OUT
+    assert (s.cpu() - os_).abs().max() <= TOL_OUT
+
+
+def test_forward_noncontiguous_image_and_single_frame():
+    """predict_controls feeds a permuted (HWC->CHW) view (autonomous_drive.py:900)."""
+    m = make_model().eval()
+    orc = O.build_oracle(0).eval()
+    img, spd, cmd, _, _ = O.synthetic_batch(1, seed=5)
+    hwc = img[0].permute(1, 2, 0).contiguous()
+    with torch.no_grad():
+        oc, os_ = orc(img, spd, cmd)
+        x = hwc.cuda().permute(2, 0, 1).unsqueeze(0)
+        assert not x.is_contiguous()
+        c, s = m(x, spd.cuda(), cmd.cuda())
+    assert (c.cpu() - oc).abs().max() <= TOL_OUT
+    assert (s.cpu() - os_).abs().max() <= TOL_OUT
+
+
+def test_forward_train_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "forward_train_b8.npz"))
+    bufs = json.load(open(os.path.join(golden_dir, "forward_train_b8_buffers.json")))
+    m = make_model().train()
+    img, spd, cmd, _, _ = O.synthetic_batch(8, seed=int(g["seed"]))
+    with torch.no_grad():
+        c, s = m(*to_dev(img, spd, cmd))
+    assert np.abs(c.cpu().numpy() - g["controls"]).max() <= TOL_OUT
+    assert np.abs(s.cpu().numpy() - g["pred_speed"]).max() <= TOL_OUT
+    sd = m.state_dict()
+    assert np.abs(sd["visual_encoder.1.running_mean"].cpu().numpy() - g["bn0_running_mean"]).max() <= 1e-5
+    assert np.abs(sd["visual_encoder.1.running_var"].cpu().numpy() - g["bn0_running_var"]).max() <= 1e-5
+    assert np.abs(sd["visual_encoder.7.2.bn2.running_var"].cpu().numpy() - g["last_running_var"]).max() <= 1e-5
+    for name, chk in bufs.items():
+        t = sd[name]
+        if name.endswith("num_batches_tracked"):
+            assert int(t) == 1
+        else:
+            assert abs(float(t.double().sum()) - chk["sum"]) <= 1e-4 * max(1.0, abs(chk["sum"]))
+
+
+def _cfgs():
+    from cilrs_mi355 import CONFIG_A, CONFIG_B, TrainConfig
+    b = TrainConfig(**{**CONFIG_B.__dict__, "dropout": 0.0})     # parity runs use dropout 0
+    return {"A": (CONFIG_A, O.CONFIG_A), "B": (b, O.CONFIG_B)}
+
+
+def _grad_views(eng):
+    return {n: g for (n, _, _, _), g in zip(eng.params_layout, eng.grad_views)}
+
+
+@pytest.mark.parametrize("cfg_name", ["A", "B"])
+def test_train_steps_golden_and_oracle(golden_dir, cfg_name):
+    """Three fused train steps (forward, loss, backward, [clip], Adam): loss dicts, step-1
+    gradients, parameters after steps 1 and 3 -- vs the golden file AND the live oracle."""
+    from cilrs_mi355 import Trainer
+    cfg, ocfg = _cfgs()[cfg_name]
+    ref = json.load(open(os.path.join(golden_dir, f"step_cfg{cfg_name}_b8.json")))
+    m = make_model()
+    tr = Trainer(m, cfg)
+    orc = O.build_oracle(0)
+    oopt = O.make_optimizer(orc, ocfg)
+    for s, seed in enumerate(ref["seeds"]):
+        imgs, spds, cmds, tgts = O.synthetic_batch(8, seed=seed)[:4]
+        tr.train_step(*to_dev(imgs, spds, cmds, tgts))
+        got = tr.losses()
+        old, ognorm = O.train_step(orc, oopt, ocfg, imgs, spds, cmds, tgts)
+        for k, v in ref["steps"][s]["loss"].items():
+            assert abs(got[k] - v) <= 1e-4 * max(1.0, abs(v)), (s, k, got[k], v)
+            assert abs(got[k] - old[k]) <= 1e-4 * max(1.0, abs(v))
+        if s == 0:
+            coef = 1.0
+            if cfg.grad_clip > 0:
+                gn = tr.grad_norm()
+                assert abs(gn - ref["steps"][0]["gnorm"]) <= 2e-4 * ref["steps"][0]["gnorm"]
+                coef = min(1.0, cfg.grad_clip / (gn + 1e-6))
+            gv = _grad_views(tr.eng)
+            worst = 0.0
+            for n, p in orc.named_parameters():
+                mine = gv[n].detach().cpu() * coef
+                want = p.grad                       # post-clip, like the fixture
+                err = float((mine - want).abs().max())
+                scale = max(1.0, float(want.abs().max()))
+                worst = max(worst, err / scale)
+                assert err <= 2e-4 * scale, (n, err, scale)
+                chk = ref["steps"][0]["grads"][n]
+                assert abs(float(mine.double().norm()) - chk["l2"]) <= 2e-4 * max(1.0, chk["l2"])
+                flat = mine.flatten()
+                idx = [0, flat.numel() // 3, (2 * flat.numel()) // 3, flat.numel() - 1]
+                for i, sv in zip(idx, chk["samples"]):
+                    assert abs(float(flat[i]) - sv) <= 2e-4 * scale, (n, i)
+            print(f"cfg {cfg_name}: worst relative grad error {worst:.3e}")
+        if ref["steps"][s]["params"] is not None:
+            pv = dict(m.named_parameters())
+            for n, p in orc.named_parameters():
+                mine = pv[n].detach().cpu()
+                # |update| <= ~lr per step; allow summation noise through Adam's normalisation
+                assert (mine - p.detach()).abs().max() <= 5e-5, (s, n)
+                chk = ref["steps"][s]["params"][n]
+                assert abs(float(mine.double().sum()) - chk["sum"]) <= 2e-3 + 1e-5 * abs(chk["sum"])
+    # BN running statistics after 3 steps
+    sd = m.state_dict()
+    for name, chk in ref["buffers"].items():
+        if name.endswith("num_batches_tracked"):
+            assert int(sd[name]) == 3
+        else:
+            assert abs(float(sd[name].double().sum()) - chk["sum"]) <= 2e-4 * max(1.0, abs(chk["sum"]))
+
+
+def test_autograd_path_matches_fused_step():
+    """loss.backward() + torch.optim.Adam over model.parameters() (the reference's own loop,
+    notebook/notebook.ipynb:549-555) drives the same kernels as Trainer.train_step."""
+    from cilrs_mi355 import CONFIG_A, Trainer
+    imgs, spds, cmds, tgts = to_dev(*O.synthetic_batch(8, seed=31)[:4])
+    m1 = make_model()
+    tr = Trainer(m1, CONFIG_A)
+    tr.train_step(imgs, spds, cmds, tgts)
+
+    m2 = make_model().train()
+    opt = torch.optim.Adam(m2.parameters(), lr=CONFIG_A.lr, weight_decay=CONFIG_A.weight_decay)
+    pc, ps = m2(imgs, spds, cmds)
+    assert pc.requires_grad and ps.requires_grad
+    loss = torch.nn.functional.mse_loss(pc, tgts) + 0.05 * torch.nn.functional.mse_loss(ps, spds)
+    opt.zero_grad()
+    loss.backward()
+    g1 = _grad_views(tr.eng)
+    for n, p in m2.named_parameters():
+        assert p.grad is not None
+        assert (p.grad - g1[n]).abs().max() <= 1e-6 * max(1.0, float(g1[n].abs().max())), n
+    opt.step()
+    for (n, a), (_, b) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert (a - b).abs().max() <= 2e-6, n
+    assert abs(float(loss) - tr.losses()["total"]) <= 1e-5
+
+
+def test_predictor_matches_golden(golden_dir):
+    from cilrs_mi355.predict import Predictor
+    g = json.load(open(os.path.join(golden_dir, "infer_pipeline.json")))
+    frame = np.floor(O._hash_u01(g["frame_seed"], g["frame_stream"], 88 * 200 * 3) * 256)
+    frame = frame.astype(np.uint8).reshape(88, 200, 3)
+    pr = Predictor(make_model())
+    for case in g["cases"]:
+        out = pr.predict_controls(frame, case["speed_kmh"], case["command"])
+        want = case["out"]
+        assert len(out) == 4
+        for a, b, tol in zip(out, want, (1e-4, 1e-4, 1e-4, 90 * 1e-4)):
+            assert abs(a - b) <= tol, (case, out, want)
+
+
+def test_invalid_inputs_raise():
+    m = make_model().eval()
+    img, spd, cmd, _, _ = O.synthetic_batch(2, seed=3)
+    with pytest.raises(RuntimeError):
+        m(img.cuda(), spd.cuda(), cmd.cuda().int())          # command must be int64
+    with pytest.raises(RuntimeError):
+        m(img.cuda()[:, :2], spd.cuda(), cmd.cuda())           # 3 channels
+    with pytest.raises(RuntimeError):
+        m(img, spd.cuda(), cmd.cuda())                         # device mismatch
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    """checkpoint_best.pth layout (notebook.ipynb:631-636) loads into the reference-shaped class
+    with strict=True (autonomous_drive.py:496-497) and resumes the fused trainer bit-exactly."""
+    from cilrs_mi355 import CONFIG_A, Trainer, checkpoint
+    m = make_model()
+    tr = Trainer(m, CONFIG_A)
+    b0 = to_dev(*O.synthetic_batch(4, seed=41)[:4])
+    b1 = to_dev(*O.synthetic_batch(4, seed=42)[:4])
+    tr.train_step(*b0)
+    path = str(tmp_path / "checkpoint_best.pth")
+    checkpoint.save_best(path, m, tr, epoch=1, val_loss=0.123, val_steer=0.01,
+                         cmd_steer_errors={"FOLLOW": 0.1, "LEFT": 0.2, "RIGHT": 0.3, "STRAIGHT": 0.4})
+    ck = torch.load(path, map_location="cpu", weights_only=True)
+    assert {"epoch", "model_state_dict", "optimizer_state_dict", "val_loss", "val_steer", "config",
+            "cmd_steer_errors"} <= set(ck)
+    ref_shaped = O.CILRSOracle()
+    ref_shaped.load_state_dict(ck["model_state_dict"], strict=True)
+    opt = torch.optim.Adam(ref_shaped.parameters(), lr=CONFIG_A.lr)
+    opt.load_state_dict(ck["optimizer_state_dict"])                # torch-Adam format
+    assert len(ck["optimizer_state_dict"]["state"]) == 142
+    for k, v in ck["model_state_dict"].items():
+        assert v.is_contiguous() and v.device.type == "cpu"
+    # resume
+    tr.train_step(*b1)
+    want = {n: p.detach().clone() for n, p in m.named_parameters()}
+    m2 = make_model(seed=9)
+    tr2 = Trainer(m2, CONFIG_A)
+    checkpoint.load(path, m2, tr2)
+    tr2.train_step(*b1)
+    for n, p in m2.named_parameters():
+        assert torch.equal(p.detach(), want[n]), n
+
+
+def test_dropout_training_runs_and_is_deterministic():
+    from cilrs_mi355 import CONFIG_B, Trainer
+    torch.manual_seed(123)
+    batch = to_dev(*O.synthetic_batch(8, seed=51)[:4])
+    outs = []
+    for _ in range(2):
+        torch.manual_seed(123)
+        m = make_model(dropout=0.5)
+        tr = Trainer(m, CONFIG_B)
+        tr.train_step(*batch)
+        outs.append((tr.losses()["total"], m.state_dict()["control_branches.0.3.weight"].clone()))
+    assert np.isfinite(outs[0][0])
+    assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1])

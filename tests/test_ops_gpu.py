@@ -1,0 +1,279 @@
+"""Op-level parity of the HIP kernels (through the C-ABI) against torch fp32 CPU ops -- the ops
+the reference's path dispatches.  Tolerances are stated per test; matrix work is
+exact-f32 MFMA (an fmaf chain), so differences are summation-order only."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from cilrs_mi355 import _lib as L
+    return L
+
+
+def dev(t):
+    return t.contiguous().cuda()
+
+
+def nhwc(t):      # NCHW cpu -> NHWC gpu
+    return t.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def ohwi(w):      # OIHW cpu -> OHWI gpu
+    return w.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# (N, H, W, Cin, Cout, k, stride, pad) -- the real trunk shapes at small batch + odd tails
+CONV_CASES = [
+    (3, 22, 50, 64, 64, 3, 1, 1),      # layer1
+    (2, 22, 50, 64, 128, 3, 2, 1),     # layer2.0.conv1 (stride 2)
+    (2, 22, 50, 64, 128, 1, 2, 0),     # layer2 downsample
+    (3, 11, 25, 128, 128, 3, 1, 1),    # layer2
+    (2, 11, 25, 128, 256, 3, 2, 1),    # layer3.0.conv1
+    (5, 6, 13, 256, 256, 3, 1, 1),     # layer3
+    (2, 6, 13, 256, 512, 1, 2, 0),     # layer4 downsample
+    (7, 3, 7, 512, 512, 3, 1, 1),      # layer4
+    (1, 3, 7, 512, 512, 3, 1, 1),      # single frame (M = 21)
+]
+
+
+def _tol(ref, scale=2e-5):
+    return scale * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("cfg,splitk", [(-1, 0), (0, 1), (1, 1), (2, 1), (1, 3), (2, 2)])
+def test_conv_fwd(case, cfg, splitk):
+    L = _lib()
+    lib = L.lib()
+    N, H, W, Cin, Cout, k, s, p = case
+    if cfg == 0 and Cout % 128:
+        pytest.skip("128-wide tile needs Cout % 128 == 0")
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (k * k * Cin) ** 0.5
+    ref = F.conv2d(x, w, None, s, p)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    y = torch.full((N, Ho, Wo, Cout), float("nan"), device="cuda")
+    scratch = torch.empty(8 * y.numel(), device="cuda")
+    xd, wd = nhwc(x), ohwi(w)
+    L.check(lib.cilrs_conv2d_fwd(L.ptr(xd), L.ptr(wd), L.ptr(y), N, H, W, Cin, Cout, k, k, s, p,
+                                 cfg, splitk, L.ptr(scratch), scratch.numel(), stream()))
+    torch.cuda.synchronize()
+    got = y.cpu().permute(0, 3, 1, 2)
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max() <= _tol(ref)
+
+
+def test_conv_fwd_stem():
+    """7x7/s2/p3, Cin = 3 padded to 4 (generic-tap path)."""
+    L = _lib()
+    lib = L.lib()
+    N, H, W = 2, 88, 200
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(N, 3, H, W, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) / 147 ** 0.5
+    ref = F.conv2d(x, w, None, 2, 3)
+    x4 = torch.zeros(N, H, W, 4)
+    x4[..., :3] = x.permute(0, 2, 3, 1)
+    w4 = torch.zeros(64, 7, 7, 4)
+    w4[..., :3] = w.permute(0, 2, 3, 1)
+    y = torch.full((N, 44, 100, 64), float("nan"), device="cuda")
+    x4d, w4d = dev(x4), dev(w4)          # keep alive: ptr() does not hold a reference
+    L.check(lib.cilrs_conv2d_fwd(L.ptr(x4d), L.ptr(w4d), L.ptr(y), N, H, W, 4, 64, 7, 7,
+                                 2, 3, -1, 0, None, 0, stream()))
+    torch.cuda.synchronize()
+    got = y.cpu().permute(0, 3, 1, 2)
+    assert (got - ref).abs().max() <= _tol(ref)
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("cfg,splitk,with_addend", [(-1, 0, False), (1, 1, True), (2, 2, True)])
+def test_conv_dgrad(case, cfg, splitk, with_addend):
+    L = _lib()
+    lib = L.lib()
+    N, H, W, Cin, Cout, k, s, p = case
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(N, Cin, H, W, generator=g, requires_grad=True)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (k * k * Cin) ** 0.5
+    y = F.conv2d(x, w, None, s, p)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    ref = x.grad
+    add = torch.randn(N, H, W, Cin, generator=g) if with_addend else None
+    dx = torch.full((N, H, W, Cin), float("nan"), device="cuda")
+    scratch = torch.empty(8 * dx.numel(), device="cuda")
+    addd = dev(add) if with_addend else None
+    dyd, wd = nhwc(dy), ohwi(w)
+    L.check(lib.cilrs_conv2d_dgrad(L.ptr(dyd), L.ptr(wd), L.ptr(dx), L.ptr(addd), N, H,
+                                   W, Cin, Cout, k, k, s, p, cfg, splitk, L.ptr(scratch),
+                                   scratch.numel(), stream()))
+    torch.cuda.synchronize()
+    got = dx.cpu()
+    want = ref.permute(0, 2, 3, 1)
+    if with_addend:
+        want = want + add
+    assert torch.isfinite(got).all()
+    assert (got - want).abs().max() <= _tol(want)
+
+
+@pytest.mark.parametrize("case", CONV_CASES + [(4, 22, 50, 64, 64, 3, 1, 1)])
+def test_conv_wgrad(case):
+    L = _lib()
+    lib = L.lib()
+    N, H, W, Cin, Cout, k, s, p = case
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g, requires_grad=True)
+    y = F.conv2d(x, w, None, s, p)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    ref = w.grad.permute(0, 2, 3, 1)
+    nsc = lib.cilrs_conv2d_wgrad_scratch_floats(N, H, W, Cin, Cout, k, k, s, p)
+    scratch = torch.empty(nsc, device="cuda")
+    dw = torch.full((Cout, k, k, Cin), float("nan"), device="cuda")
+    xd, dyd = nhwc(x), nhwc(dy)
+    L.check(lib.cilrs_conv2d_wgrad(L.ptr(xd), L.ptr(dyd), L.ptr(dw), L.ptr(scratch), N,
+                                   H, W, Cin, Cout, k, k, s, p, Cin, stream()))
+    torch.cuda.synchronize()
+    got = dw.cpu()
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max() <= _tol(ref, 3e-5)
+
+
+def test_conv_wgrad_stem():
+    L = _lib()
+    lib = L.lib()
+    N, H, W = 2, 88, 200
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, 3, H, W, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g, requires_grad=True)
+    y = F.conv2d(x, w, None, 2, 3)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    ref = w.grad.permute(0, 2, 3, 1)
+    x4 = torch.zeros(N, H, W, 4)
+    x4[..., :3] = x.permute(0, 2, 3, 1)
+    nsc = lib.cilrs_conv2d_wgrad_scratch_floats(N, H, W, 4, 64, 7, 7, 2, 3)
+    scratch = torch.empty(nsc, device="cuda")
+    dw = torch.full((64, 7, 7, 3), float("nan"), device="cuda")
+    x4d, dyd = dev(x4), nhwc(dy)
+    L.check(lib.cilrs_conv2d_wgrad(L.ptr(x4d), L.ptr(dyd), L.ptr(dw), L.ptr(scratch), N,
+                                   H, W, 4, 64, 7, 7, 2, 3, 3, stream()))
+    torch.cuda.synchronize()
+    got = dw.cpu()
+    assert (got - ref).abs().max() <= _tol(ref, 3e-5)
+
+
+@pytest.mark.parametrize("M,Cc", [(3 * 22 * 50, 64), (5 * 275, 128), (2 * 78, 256), (21, 512),
+                                  (8 * 4400, 64)])
+@pytest.mark.parametrize("relu,res", [(1, False), (1, True), (0, False)])
+def test_bn_train_fwd_bwd(M, Cc, relu, res):
+    L = _lib()
+    lib = L.lib()
+    g = torch.Generator().manual_seed(6)
+    y = (torch.randn(M, Cc, generator=g) * 1.7 + 0.3).requires_grad_(True)
+    gamma = (torch.rand(Cc, generator=g) + 0.5).requires_grad_(True)
+    beta = (torch.rand(Cc, generator=g) - 0.5).requires_grad_(True)
+    rm = torch.rand(Cc, generator=g) - 0.5
+    rv = torch.rand(Cc, generator=g) + 0.5
+    resid = torch.randn(M, Cc, generator=g) if res else None
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    # torch reference on [M,C,1,1]
+    out = F.batch_norm(y.view(M, Cc, 1, 1), rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5)
+    out = out.view(M, Cc)
+    if res:
+        out = out + resid
+    if relu:
+        out = F.relu(out)
+    dz = torch.randn(M, Cc, generator=g)
+    out.backward(dz)
+
+    yd, gd, bd, rmd, rvd = dev(y.detach()), dev(gamma.detach()), dev(beta.detach()), dev(rm), dev(rv)
+    nbt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    stats = torch.empty(4 * Cc, device="cuda")
+    part = torch.empty(lib.cilrs_bn_partial_floats(Cc), device="cuda")
+    z = torch.empty(M, Cc, device="cuda")
+    resd = dev(resid) if res else None
+    L.check(lib.cilrs_bn_train_fwd(L.ptr(yd), M, Cc, L.ptr(gd), L.ptr(bd), L.ptr(rmd), L.ptr(rvd),
+                                   L.ptr(nbt), 0.1, 1e-5, L.ptr(resd), relu, L.ptr(stats),
+                                   L.ptr(part), L.ptr(z), stream()))
+    torch.cuda.synchronize()
+    assert (z.cpu() - out.detach()).abs().max() <= 2e-5 * max(1.0, float(out.abs().max()))
+    assert (rmd.cpu() - rm_ref).abs().max() <= 1e-6
+    assert (rvd.cpu() - rv_ref).abs().max() <= 1e-5
+    assert int(nbt.item()) == 1
+
+    dgamma = torch.empty(Cc, device="cuda")
+    dbeta = torch.empty(Cc, device="cuda")
+    coef = torch.empty(3 * Cc, device="cuda")
+    dy = torch.empty(M, Cc, device="cuda")
+    gout = torch.empty(M, Cc, device="cuda")
+    dzd = dev(dz)
+    L.check(lib.cilrs_bn_bwd(L.ptr(dzd), L.ptr(z), L.ptr(yd), M, Cc, L.ptr(gd), L.ptr(stats),
+                             relu, L.ptr(dgamma), L.ptr(dbeta), L.ptr(coef), L.ptr(part),
+                             L.ptr(dy), L.ptr(gout), stream()))
+    torch.cuda.synchronize()
+    sc = max(1.0, float(y.grad.abs().max()))
+    assert (dy.cpu() - y.grad).abs().max() <= 5e-5 * sc
+    gs = max(1.0, float(gamma.grad.abs().max()))
+    assert (dgamma.cpu() - gamma.grad).abs().max() <= 5e-5 * gs
+    assert (dbeta.cpu() - beta.grad).abs().max() <= 5e-5 * max(1.0, float(beta.grad.abs().max()))
+    mask = (out.detach() > 0).float() if relu else torch.ones(M, Cc)
+    assert (gout.cpu() - dz * mask).abs().max() == 0.0
+
+
+def test_bn_eval_fwd():
+    L = _lib()
+    lib = L.lib()
+    M, Cc = 1100, 64
+    g = torch.Generator().manual_seed(7)
+    y = torch.randn(M, Cc, generator=g)
+    gamma, beta = torch.rand(Cc, generator=g) + 0.5, torch.rand(Cc, generator=g) - 0.5
+    rm, rv = torch.rand(Cc, generator=g) - 0.5, torch.rand(Cc, generator=g) + 0.5
+    ref = F.relu(F.batch_norm(y.view(M, Cc, 1, 1), rm, rv, gamma, beta, False, 0.1, 1e-5)).view(M, Cc)
+    stats = torch.empty(4 * Cc, device="cuda")
+    z = torch.empty(M, Cc, device="cuda")
+    yd, gd, bd, rmd, rvd = dev(y), dev(gamma), dev(beta), dev(rm), dev(rv)
+    L.check(lib.cilrs_bn_eval_fwd(L.ptr(yd), M, Cc, L.ptr(gd), L.ptr(bd),
+                                  L.ptr(rmd), L.ptr(rvd), 1e-5, None, 1, L.ptr(stats),
+                                  L.ptr(z), stream()))
+    torch.cuda.synchronize()
+    assert (z.cpu() - ref).abs().max() <= 1e-5
+
+
+@pytest.mark.parametrize("N,H,W", [(2, 44, 100), (1, 7, 9), (3, 8, 8)])
+def test_maxpool(N, H, W):
+    L = _lib()
+    lib = L.lib()
+    Cc = 64
+    g = torch.Generator().manual_seed(8)
+    x = F.relu(torch.randn(N, Cc, H, W, generator=g)).requires_grad_(True)   # many exact-zero ties
+    out = F.max_pool2d(x, 3, 2, 1)
+    dout = torch.randn(out.shape, generator=g)
+    out.backward(dout)
+    Ho, Wo = out.shape[2], out.shape[3]
+    xd = nhwc(x.detach())
+    o = torch.empty(N, Ho, Wo, Cc, device="cuda")
+    am = torch.empty(N, Ho, Wo, Cc, dtype=torch.uint8, device="cuda")
+    L.check(lib.cilrs_maxpool_fwd(L.ptr(xd), L.ptr(o), L.ptr(am), N, H, W, Cc, stream()))
+    dx = torch.empty(N, H, W, Cc, device="cuda")
+    doutd = nhwc(dout)
+    L.check(lib.cilrs_maxpool_bwd(L.ptr(doutd), L.ptr(am), L.ptr(dx), N, H, W, Cc, stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(o.cpu().permute(0, 3, 1, 2), out.detach())
+    # ties only occur at relu zeros, where the later ReLU mask kills the gradient anyway:
+    # compare where the input is positive
+    pos = (x.detach() > 0)
+    got = dx.cpu().permute(0, 3, 1, 2)
+    assert (got[pos] - x.grad[pos]).abs().max() <= 1e-6
+    assert abs(float(got.sum()) - float(x.grad.sum())) <= 1e-2
