@@ -52,7 +52,11 @@ def cpu_baseline(batch, steps=2):
     the same batch after one warm-up, plus 20 single-frame eval forwards."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import cilrs_oracle as O
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))      # a 1-GPU box's CPU share is 16 cores
     torch.set_num_threads(cores)
     m = O.build_oracle(0)
     opt = O.make_optimizer(m, O.CONFIG_A)
@@ -74,6 +78,10 @@ def cpu_baseline(batch, steps=2):
                 sample=f"{steps} Config-A train steps at B={batch} (after 1 warm-up) with "
                        f"torch.set_num_threads({cores}); infer = mean of 20 B=1 eval forwards",
                 infer_ms=round(infer_ms, 3))
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
 def main():
@@ -117,9 +125,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    log(f"rank {rank}/{world}: model + trainer ready, warm-up {args.warmup} steps")
     for _ in range(args.warmup):
         trainer.train_step(*batch)
     sync()
+    log("timed region")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record()
@@ -157,6 +167,7 @@ def main():
             value * TRAIN_GFLOP_PER_FRAME / 1e3 / world / PEAK_F32_MATRIX_TFLOPS, 4),
     }
 
+    log(f"{value:.1f} frames/s, {wall / args.steps * 1e3:.3f} ms/step")
     if world == 1:
         # ---- per-kernel hipEvent timing on the launch stream (extra steps, same step fn) ----
         pl = trainer.eng.plan(args.batch, 88, 200)
@@ -201,6 +212,7 @@ def main():
                 "tflops": round(r["flops"] / max(r["ms"], 1e-9) / 1e9, 2) if r["flops"] else None}
             for l, r in sorted(table.items()) if l.startswith("conv_")}
 
+        log("per-kernel profile done; inference latency")
         # ---- single-frame inference latency (predict_controls path) ----
         from cilrs_mi355.predict import Predictor
         pr = Predictor(model)
@@ -216,6 +228,7 @@ def main():
         out["infer_ms"] = round(lat[len(lat) // 2], 4)
         model.train()
 
+        log(f"infer {out['infer_ms']} ms; cpu baseline" )
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.batch)
     print(json.dumps(out))

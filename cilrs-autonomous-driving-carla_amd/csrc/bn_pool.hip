@@ -16,7 +16,7 @@ namespace cilrs {
 
 namespace {
 
-constexpr int kMaxPartBlocks = 512;
+constexpr int kMaxPartBlocks = 1024;
 
 // partial[blk][0][c] = sum_rows v1, partial[blk][1][c] = sum_rows v2
 // MODE 0: v1 = y, v2 = y*y                     (forward statistics)
@@ -39,24 +39,40 @@ __global__ __launch_bounds__(256) void bn_colreduce_kernel(
         mean = *reinterpret_cast<const f32x4*>(stats + q * 4);
         rstd = *reinterpret_cast<const f32x4*>(stats + C + q * 4);
     }
-    if (rsub < rpi) {
-        for (int r = row_begin + rsub; r < row_end; r += rpi) {
-            const size_t o = (size_t)r * C + q * 4;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(y + o);
-            if (MODE == 0) {
-                s1 += v;
-                s2 += v * v;
-            } else {
-                f32x4 g = *reinterpret_cast<const f32x4*>(dz + o);
-                if (relu) {
-                    const f32x4 zz = *reinterpret_cast<const f32x4*>(z + o);
+    auto accum = [&](int r, f32x4& a1, f32x4& a2) {
+        const size_t o = (size_t)r * C + q * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(y + o);
+        if (MODE == 0) {
+            a1 += v;
+            a2 += v * v;
+        } else {
+            f32x4 g = *reinterpret_cast<const f32x4*>(dz + o);
+            if (relu) {
+                const f32x4 zz = *reinterpret_cast<const f32x4*>(z + o);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) g[e] = zz[e] > 0.f ? g[e] : 0.f;
-                }
-                s1 += g;
-                s2 += g * ((v - mean) * rstd);
+                for (int e = 0; e < 4; ++e) g[e] = zz[e] > 0.f ? g[e] : 0.f;
             }
+            a1 += g;
+            a2 += g * ((v - mean) * rstd);
         }
+    };
+    {
+        // four independent row streams per thread: 4x the bytes in flight, and a shallower
+        // summation tree (fixed order => deterministic)
+        f32x4 t1[4], t2[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            t1[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            t2[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        int r = row_begin + rsub;
+        for (; r + 3 * rpi < row_end; r += 4 * rpi) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) accum(r + u * rpi, t1[u], t2[u]);
+        }
+        for (; r < row_end; r += rpi) accum(r, t1[0], t2[0]);
+        s1 = (t1[0] + t1[1]) + (t1[2] + t1[3]);
+        s2 = (t2[0] + t2[1]) + (t2[2] + t2[3]);
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -77,19 +93,38 @@ __global__ __launch_bounds__(256) void bn_colreduce_kernel(
     }
 }
 
+// Sum the per-block partials of 32 channels: 8 thread groups stride over the blocks in double,
+// then a fixed-order LDS combine (deterministic).  Returns the two sums to threads g == 0.
+__device__ __forceinline__ bool partial_sums(const float* __restrict__ partial, const int nblk,
+                                             const int C, int& c, double& s1, double& s2) {
+    __shared__ double red[2][8][32];
+    const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
+    c = blockIdx.x * 32 + cl;
+    double a1 = 0.0, a2 = 0.0;
+    if (c < C)
+        for (int b = g; b < nblk; b += 8) {
+            a1 += (double)partial[(size_t)b * 2 * C + c];
+            a2 += (double)partial[(size_t)b * 2 * C + C + c];
+        }
+    red[0][g][cl] = a1;
+    red[1][g][cl] = a2;
+    __syncthreads();
+    if (g != 0 || c >= C) return false;
+    s1 = 0.0; s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { s1 += red[0][k][cl]; s2 += red[1][k][cl]; }
+    return true;
+}
+
 // stats layout (floats): [0,C) mean | [C,2C) rstd | [2C,3C) w = gamma*rstd | [3C,4C) b = beta-mean*w
-__global__ void bn_fwd_finalize_kernel(const float* __restrict__ partial, const int nblk,
-                                       const int M, const int C, const float* __restrict__ gamma,
-                                       const float* __restrict__ beta, float* running_mean,
-                                       float* running_var, long long* nbt, const float momentum,
-                                       const float eps, float* __restrict__ stats) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-        s1 += (double)partial[(size_t)b * 2 * C + c];
-        s2 += (double)partial[(size_t)b * 2 * C + C + c];
-    }
+__global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(
+    const float* __restrict__ partial, const int nblk, const int M, const int C,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
+    float* running_var, long long* nbt, const float momentum, const float eps,
+    float* __restrict__ stats) {
+    int c;
+    double s1, s2;
+    if (!partial_sums(partial, nblk, C, c, s1, s2)) return;
     const double mean = s1 / M;
     double var = s2 / M - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -147,18 +182,13 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 }
 
 // coef layout: [0,C) c1 = gamma*rstd | [C,2C) c2 = sum(g)/M | [2C,3C) c3 = sum(g*xhat)/M
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, const int nblk,
-                                       const int M, const int C, const float* __restrict__ gamma,
-                                       const float* __restrict__ stats, float* dgamma,
-                                       float* dbeta, float* __restrict__ coef,
-                                       const int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-        s1 += (double)partial[(size_t)b * 2 * C + c];
-        s2 += (double)partial[(size_t)b * 2 * C + C + c];
-    }
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
+    const float* __restrict__ partial, const int nblk, const int M, const int C,
+    const float* __restrict__ gamma, const float* __restrict__ stats, float* dgamma,
+    float* dbeta, float* __restrict__ coef, const int accumulate) {
+    int c;
+    double s1, s2;
+    if (!partial_sums(partial, nblk, C, c, s1, s2)) return;
     const float db = (float)s1, dg = (float)s2;
     dbeta[c] = accumulate ? dbeta[c] + db : db;
     dgamma[c] = accumulate ? dgamma[c] + dg : dg;
@@ -325,9 +355,11 @@ int grid_for(size_t total, int per_block = 256, int cap = 4096) {
 struct ColPlan { int nblk; int rows_per_block; };
 ColPlan col_plan(int M, int C) {
     const int rpi = 256 / (C >> 2);
+    // >= 8 iterations of the 4-way unrolled loop per block when M allows, <= kMaxPartBlocks blocks
     int rows = cdiv(M, kMaxPartBlocks);
-    rows = cdiv(rows, rpi) * rpi;          // whole iterations
-    if (rows < rpi) rows = rpi;
+    const int min_rows = 16 * rpi;
+    if (rows < min_rows) rows = min_rows;
+    rows = cdiv(rows, rpi) * rpi;
     ColPlan p{cdiv(M, rows), rows};
     return p;
 }
@@ -351,7 +383,7 @@ int launch_bn_train_fwd(const float* y, int M, int C, const float* gamma, const 
     bn_colreduce_kernel<0><<<p.nblk, 256, 0, s>>>(y, nullptr, nullptr, nullptr, partial, M, C, 0,
                                                   p.rows_per_block);
     CILRS_LAUNCH_CHECK();
-    bn_fwd_finalize_kernel<<<cdiv(C, 128), 128, 0, s>>>(partial, p.nblk, M, C, gamma, beta,
+    bn_fwd_finalize_kernel<<<cdiv(C, 32), 256, 0, s>>>(partial, p.nblk, M, C, gamma, beta,
                                                         running_mean, running_var, nbt, momentum,
                                                         eps, stats);
     CILRS_LAUNCH_CHECK();
@@ -385,7 +417,7 @@ int launch_bn_bwd(const float* dz, const float* z, const float* y, int M, int C,
     bn_colreduce_kernel<1><<<p.nblk, 256, 0, s>>>(y, dz, z, stats, partial, M, C, relu,
                                                   p.rows_per_block);
     CILRS_LAUNCH_CHECK();
-    bn_bwd_finalize_kernel<<<cdiv(C, 128), 128, 0, s>>>(partial, p.nblk, M, C, gamma, stats,
+    bn_bwd_finalize_kernel<<<cdiv(C, 32), 256, 0, s>>>(partial, p.nblk, M, C, gamma, stats,
                                                         dgamma, dbeta, coef, accumulate);
     CILRS_LAUNCH_CHECK();
     const size_t total4 = (size_t)M * C / 4;

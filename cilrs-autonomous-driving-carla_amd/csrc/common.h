@@ -56,20 +56,27 @@ static inline size_t cdivz(size_t a, size_t b) { return (a + b - 1) / b; }
 struct ConvArgs {
     const float* x;        // gathered operand: [N][H][W] pixels, x_ld floats apart, Cin used
     const float* w;        // weights (OHWI of the FORWARD conv)
-    float* y;              // [M][y_ld], Cout columns written
-    const float* addend;   // optional [M][y_ld]: y = acc + addend (may alias y)
+    float* y;              // [N][out_H][out_W] pixels, y_ld floats apart, Cout columns written
+    const float* addend;   // optional, y's layout: y = acc + addend (may alias y)
     const float* bias;     // optional [Cout]
-    const float* mask;     // optional [M][mask_ld]: y = (mask > 0) ? y * mask_scale : 0
+    const float* mask;     // optional, pixel-indexed like y, mask_ld apart:
+                           //   y = (mask > 0) ? y * mask_scale : 0
     int N, H, W, Cin;      // geometry of the tensor the A-gather reads
-    int Ho, Wo, Cout;      // geometry of the tensor written (M = N*Ho*Wo rows, Cout columns)
-    int KH, KW;
-    int stride, pad;       // output pixel -> (up-sampled) input pixel: o*stride - pad + k
-    int dil;               // input dilation (dgrad of a strided conv), 1 otherwise
+    int Ho, Wo, Cout;      // ENUMERATED output grid (M = N*Ho*Wo rows), Cout columns
+    int KH, KW;            // filter size (generic-tap path and weight row pitch)
+    int stride, pad;       // enumerated output pixel -> base input pixel: o*stride - pad
     int x_ld, y_ld, mask_ld;
     int w_mode;            // 0: B is k-contiguous (forward); 1: dgrad (B rows = forward Cout)
-    int w_cin;             // forward conv's Cin (row pitch of OHWI), used in w_mode 1
+    int w_cin;             // forward conv's Cin (OHWI row pitch), used in w_mode 1
     int relu;
     float mask_scale;
+    // where enumerated output pixel (n, oh, ow) lands in y / addend / mask:
+    //   pixel (n, oh*out_sh + out_h0, ow*out_sw + out_w0) of an [N][out_H][out_W] tensor
+    int out_H, out_W, out_sh, out_sw, out_h0, out_w0;
+    // filter taps visited (uniform path): input pixel = base + (tap_dh, tap_dw), weights of
+    // forward tap tap_w.  ntaps == 0 on entry => launcher fills the dense KHxKW table.
+    int ntaps;
+    int tap_dh[16], tap_dw[16], tap_w[16];
     float* scratch;        // optional split-K scratch (>= 2*M*y_ld floats to be considered)
     size_t scratch_floats;
     int force_cfg;         // -1 auto; 0: 128x128, 1: 128x64, 2: 64x64 block tile (tests/tuning)
@@ -77,6 +84,17 @@ struct ConvArgs {
     int splitk;            // set by the launcher
 };
 int launch_conv_igemm(const ConvArgs& a, hipStream_t s);
+// Data gradient of a forward conv (stride 1 or 2): dx[N,H,W,Cin] = dgrad(dy[N,Ho,Wo,Cout]) (+addend).
+// Stride 2 is decomposed into the four output-parity classes, each a dense stride-1 problem over
+// its own tap subset (no multiplications by the zeros of an up-sampled dy).
+struct DgradArgs {
+    const float* dy; const float* w; float* dx; const float* addend;
+    const float* mask; int mask_ld; float mask_scale;
+    int N, H, W, Cin, Ho, Wo, Cout, K, stride, pad;
+    int dy_ld, dx_ld;
+    float* scratch; size_t scratch_floats; int force_cfg, force_splitk;
+};
+int launch_conv_dgrad(const DgradArgs& a, hipStream_t s);
 
 // ---- weight gradient (conv_wgrad.hip) --------------------------------------------------------
 struct WgradArgs {

@@ -2,20 +2,26 @@
 //
 // Replaces the cuDNN/ATen convolutions that torchvision's ResNet-34 dispatches inside
 // CILRS.visual_encoder (reference model/autonomous_drive.py:365-370; shapes SURVEY.md 2b/8a) and
-// the 128..640-wide nn.Linear layers of the heads (autonomous_drive.py:371-387).
+// the 128..640-wide nn.Linear layers of the heads (autonomous_drive.py:371-387), forward and
+// data-gradient.
 //
 // GEMM view (no im2col buffer is ever materialised):
-//     M = N*Ho*Wo output pixels, N = Cout, K = KH*KW*Cin, A[m][k] gathered on the fly from the
+//     M = N*Ho*Wo output pixels, N = Cout, K = taps*Cin, A[m][k] gathered on the fly from the
 //     NHWC activation, B = OHWI weights.  A K-tile (32 floats) lies inside ONE filter tap, so the
 //     gather is a 128-byte contiguous read per output pixel (one full cache line, NHWC).
 //
-// Block = 256 threads = 4 waves; block tile BM x BN, K-tile 32; LDS double-buffered, register
-// staged (global loads for tile t+1 are in flight while tile t is multiplied).  LDS rows are
-// K-contiguous with a 4-float pad (pitch 36 floats = 144 B): a ds_read_b128 gives one lane four
-// k-values, and r -> 9r mod 16 being a bijection makes every 16-lane read group conflict-free.
-// Lane half h of the wave owns k = 8q+4h+e (e = 0..3) of each 8-k group for BOTH operands, so the
-// fmaf chain order is fixed and results are run-to-run deterministic.
+// Block = 256 threads = 4 waves; block tile BM x BN, K-tile 32.  Global loads run TWO K-tiles
+// ahead of the MFMAs (two register sets, LDS double-buffered): the measured load-to-use latency
+// under load (~4-6k cycles) is several K-tiles of MFMA work, one tile of prefetch left the matrix
+// pipe ~45 % idle (profiles/r01_prof_a).  Per-tile address work is a 64-bit add and a bit test:
+// row bases and per-row valid-tap masks are computed once, out-of-image taps read a zero page
+// (no divergent branches).  LDS rows are K-contiguous with a 4-float pad (pitch 36 floats): a
+// ds_read_b128 gives one lane four k-values and r -> 9r mod 16 being a bijection makes every
+// 16-lane read group conflict-free.  Lane half h owns k = 8q+4h+e (e = 0..3) of each 8-k group for
+// BOTH operands, so the fmaf chain order is fixed: results are run-to-run deterministic.
 #include "common.h"
+
+#include <string.h>
 
 namespace cilrs {
 
@@ -23,6 +29,8 @@ namespace {
 
 constexpr int BK = 32;
 constexpr int APITCH = BK + 4;
+
+__device__ float g_zero_page[64];   // zero-initialised; target of out-of-image gathers
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     // blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous chunk of
@@ -33,14 +41,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 template <int BM, int BN, int WM, int WN, bool TAP_UNIFORM, int W_MODE>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a, const int M,
-                                                         const int Ktot, const int KT) {
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a, const int M,
+                                                         const int Krow, const int KT) {
     static_assert(WM * WN == 4, "4 waves");
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
     constexpr int A_PASSES = BM / 32, B_PASSES = BN / 32;
     constexpr int B_FLOATS = (W_MODE == 0) ? BN * APITCH : BK * (BN + 4);
     constexpr int BPITCH1 = BN + 4;
+    constexpr int JQ = BN / 4, BROWS = 256 / JQ;     // W_MODE 1 loader shape
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                       // [2][BM][APITCH]
@@ -52,8 +61,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a, const
     const int wm = wave / WN, wn = wave % WN;
 
     const int tilesN = a.Cout / BN;
-    const int nwg = gridDim.x;
-    const int logical = xcd_remap(blockIdx.x, nwg);
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (logical / tilesN) * BM;
     const int n0 = (logical % tilesN) * BN;
 
@@ -64,103 +72,95 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a, const
         kt_begin = blockIdx.z * per;
         kt_end = min(KT, kt_begin + per);
     }
+    const int nt = max(kt_end - kt_begin, 0);
 
     // ---- per-thread gather rows (fixed for the whole K loop) --------------------------------
     const int kq = tid & 7, r0 = tid >> 3;
-    int rowN[A_PASSES], rowH[A_PASSES], rowW[A_PASSES];
+    long rowBase[A_PASSES];        // element offset of the row's base pixel (+ kq*4)
+    unsigned rowMask[A_PASSES];    // uniform path: bit t = tap t inside the image
+    int rowH[A_PASSES], rowW[A_PASSES];   // generic path only
     const int HoWo = a.Ho * a.Wo;
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i) {
         const int m = m0 + r0 + 32 * i;
+        rowMask[i] = 0u; rowBase[i] = 0; rowH[i] = -(1 << 20); rowW[i] = 0;
         if (m < M) {
             const int n = m / HoWo, rem = m - n * HoWo;
             const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
-            rowN[i] = n;
-            rowH[i] = oh * a.stride - a.pad;
-            rowW[i] = ow * a.stride - a.pad;
-        } else {
-            rowN[i] = -1; rowH[i] = 0; rowW[i] = 0;
+            const int hb = oh * a.stride - a.pad, wb = ow * a.stride - a.pad;
+            rowBase[i] = ((long)(n * a.H + hb) * a.W + wb) * a.x_ld + kq * 4;
+            if constexpr (TAP_UNIFORM) {
+                unsigned msk = 0u;
+                for (int t = 0; t < a.ntaps; ++t) {
+                    const int h = hb + a.tap_dh[t], w = wb + a.tap_dw[t];
+                    if (h >= 0 && w >= 0 && h < a.H && w < a.W) msk |= 1u << t;
+                }
+                rowMask[i] = msk;
+            } else {
+                rowH[i] = hb; rowW[i] = wb;
+            }
         }
     }
+    // weight row bases
+    long wBase[B_PASSES];
+    const long wrow = (long)a.KH * a.KW * a.w_cin;
+    const int jq = tid % JQ, kr0 = tid / JQ;
+#pragma unroll
+    for (int i = 0; i < B_PASSES; ++i) {
+        if constexpr (W_MODE == 0) wBase[i] = (long)(n0 + r0 + 32 * i) * Krow + kq * 4;
+        else wBase[i] = (long)(kr0 + BROWS * i) * wrow + n0 + jq * 4;
+    }
     const int cin_tiles = TAP_UNIFORM ? (a.Cin / BK) : 1;
+    const float* zero = g_zero_page + kq * 4;
 
-    f32x4 ra[A_PASSES], rb[B_PASSES];
+    // scalar cursor (tap, cin chunk) of the NEXT tile to load
+    int ld_tap = kt_begin / cin_tiles;
+    int ld_c = kt_begin - ld_tap * cin_tiles;
+    int ld_kt = kt_begin;
 
-    auto load_tile = [&](int kt) {
-        // ---- A: gathered activation rows ----
+    auto load_tile = [&](f32x4(&ra)[A_PASSES], f32x4(&rb)[B_PASSES]) {
         if constexpr (TAP_UNIFORM) {
-            const int tap = kt / cin_tiles;
-            const int c0 = (kt - tap * cin_tiles) * BK;
-            const int kh = tap / a.KW, kw = tap - kh * a.KW;
+            const long toff = ((long)a.tap_dh[ld_tap] * a.W + a.tap_dw[ld_tap]) * a.x_ld +
+                              ld_c * BK;
 #pragma unroll
             for (int i = 0; i < A_PASSES; ++i) {
-                const int hup = rowH[i] + kh, wup = rowW[i] + kw;
-                bool ok = (rowN[i] >= 0) && (hup >= 0) && (wup >= 0);
-                int h = hup, w = wup;
-                if (a.dil == 2) {
-                    ok = ok && (((hup | wup) & 1) == 0);
-                    h = hup >> 1; w = wup >> 1;
-                }
-                ok = ok && (h < a.H) && (w < a.W);
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (ok) {
-                    const float* p = a.x + (size_t)((rowN[i] * a.H + h) * a.W + w) * a.x_ld +
-                                     c0 + kq * 4;
-                    v = *reinterpret_cast<const f32x4*>(p);
-                }
-                ra[i] = v;
+                const bool ok = (rowMask[i] >> ld_tap) & 1u;
+                const float* p = ok ? (a.x + (rowBase[i] + toff)) : zero;
+                ra[i] = *reinterpret_cast<const f32x4*>(p);
             }
+            long koff;
+            if constexpr (W_MODE == 0) koff = (long)a.tap_w[ld_tap] * a.Cin + ld_c * BK;
+            else koff = (long)(ld_c * BK) * wrow + (long)a.tap_w[ld_tap] * a.w_cin;
+#pragma unroll
+            for (int i = 0; i < B_PASSES; ++i)
+                rb[i] = *reinterpret_cast<const f32x4*>(a.w + (wBase[i] + koff));
         } else {
             // generic: each k-quad may sit in a different tap (Cin % 4 == 0, e.g. the stem's
-            // channel-padded Cin = 4)
-            const int k = kt * BK + kq * 4;
+            // channel-padded Cin = 4); forward only
+            const int k = ld_kt * BK + kq * 4;
             const int tap = k / a.Cin, ci = k - tap * a.Cin;
             const int kh = tap / a.KW, kw = tap - kh * a.KW;
-            const bool kok = k < Ktot;
+            const bool kok = k < Krow;
 #pragma unroll
             for (int i = 0; i < A_PASSES; ++i) {
                 const int h = rowH[i] + kh, w = rowW[i] + kw;
-                const bool ok = kok && (rowN[i] >= 0) && (h >= 0) && (w >= 0) && (h < a.H) &&
-                                (w < a.W);
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (ok) {
-                    const float* p =
-                        a.x + (size_t)((rowN[i] * a.H + h) * a.W + w) * a.x_ld + ci;
-                    v = *reinterpret_cast<const f32x4*>(p);
-                }
-                ra[i] = v;
+                const bool ok = kok && (h >= 0) && (w >= 0) && (h < a.H) && (w < a.W);
+                const float* p =
+                    ok ? (a.x + (rowBase[i] - kq * 4 + ((long)kh * a.W + kw) * a.x_ld + ci))
+                       : zero;
+                ra[i] = *reinterpret_cast<const f32x4*>(p);
             }
-        }
-        // ---- B: weights ----
-        if constexpr (W_MODE == 0) {
-            const int k = kt * BK + kq * 4;
-            const bool kok = TAP_UNIFORM || (k < Ktot);
 #pragma unroll
             for (int i = 0; i < B_PASSES; ++i) {
-                const int co = n0 + r0 + 32 * i;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (kok) v = *reinterpret_cast<const f32x4*>(a.w + (size_t)co * Ktot + k);
-                rb[i] = v;
-            }
-        } else {
-            // dgrad: B[k = forward co][j = forward ci] at the FLIPPED tap
-            constexpr int JQ = BN / 4;
-            constexpr int ROWS = 256 / JQ;
-            const int tap = kt / cin_tiles;
-            const int c0 = (kt - tap * cin_tiles) * BK;
-            const int ftap = a.KH * a.KW - 1 - tap;
-            const int jq = tid % JQ, kr0 = tid / JQ;
-            const size_t wrow = (size_t)a.KH * a.KW * a.w_cin;
-#pragma unroll
-            for (int i = 0; i < B_PASSES; ++i) {
-                const int kr = kr0 + ROWS * i;
-                rb[i] = *reinterpret_cast<const f32x4*>(
-                    a.w + (size_t)(c0 + kr) * wrow + (size_t)ftap * a.w_cin + n0 + jq * 4);
+                const float* p = kok ? (a.w + (wBase[i] + (long)ld_kt * BK)) : zero;
+                rb[i] = *reinterpret_cast<const f32x4*>(p);
             }
         }
+        ++ld_kt;
+        if (++ld_c == cin_tiles) { ld_c = 0; ++ld_tap; }
     };
 
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, const f32x4(&ra)[A_PASSES], const f32x4(&rb)[B_PASSES]) {
         float* Ab = As + buf * BM * APITCH;
         float* Bb = Bs + buf * B_FLOATS;
 #pragma unroll
@@ -171,12 +171,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a, const
             for (int i = 0; i < B_PASSES; ++i)
                 *reinterpret_cast<f32x4*>(Bb + (r0 + 32 * i) * APITCH + kq * 4) = rb[i];
         } else {
-            constexpr int JQ = BN / 4;
-            constexpr int ROWS = 256 / JQ;
-            const int jq = tid % JQ, kr0 = tid / JQ;
 #pragma unroll
             for (int i = 0; i < B_PASSES; ++i)
-                *reinterpret_cast<f32x4*>(Bb + (kr0 + ROWS * i) * BPITCH1 + jq * 4) = rb[i];
+                *reinterpret_cast<f32x4*>(Bb + (kr0 + BROWS * i) * BPITCH1 + jq * 4) = rb[i];
         }
     };
 
@@ -188,17 +185,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a, const
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if (kt_begin < kt_end) {
-        load_tile(kt_begin);
-        store_tile(0);
-    }
-    __syncthreads();
-
-    int buf = 0;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const bool more = (kt + 1 < kt_end);
-        if (more) load_tile(kt + 1);
-
+    auto compute = [&](int buf) {
         const float* Ab = As + buf * BM * APITCH + (wm * WTM + l31) * APITCH + lh * 4;
         const float* Bb = Bs + buf * B_FLOATS;
 #pragma unroll
@@ -229,39 +216,93 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a, const
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e],
                                                                          acc[i][j], 0, 0, 0);
         }
-        if (more) store_tile(buf ^ 1);
+    };
+
+    // ---- main loop: loads run two tiles ahead (register sets 0/1), LDS double-buffered ----
+    f32x4 ra0[A_PASSES], rb0[B_PASSES], ra1[A_PASSES], rb1[B_PASSES];
+    if (nt > 0) load_tile(ra0, rb0);
+    if (nt > 1) load_tile(ra1, rb1);
+    if (nt > 0) store_tile(0, ra0, rb0);
+    __syncthreads();
+    for (int it = 0; it < nt; it += 2) {
+        if (it + 2 < nt) load_tile(ra0, rb0);
+        compute(0);
+        if (it + 1 < nt) store_tile(1, ra1, rb1);
         __syncthreads();
-        buf ^= 1;
+        if (it + 1 >= nt) break;
+        if (it + 3 < nt) load_tile(ra1, rb1);
+        compute(1);
+        if (it + 2 < nt) store_tile(0, ra0, rb0);
+        __syncthreads();
     }
 
     // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // Optional operands are fetched as 16 independent loads per tile (clamped row, no per-element
+    // branch) so their latency overlaps instead of serialising.
     const bool partial = a.splitk > 1;
+    const bool dense = (a.out_sh == 1) && (a.out_sw == 1) && (a.out_H == a.Ho) &&
+                       (a.out_W == a.Wo);
     float* yout = partial ? a.y + (size_t)blockIdx.z * M * a.y_ld : a.y;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int co = n0 + wn * WTN + j * 32 + l31;
+            const int mbase = m0 + wm * WTM + i * 32 + 4 * lh;
+            int pix[16];     // output pixel index of each of the 16 rows (clamped for loads)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int m = m0 + wm * WTM + i * 32 + row;
-                if (m < M) {
-                    float v = acc[i][j][r];
-                    const size_t o = (size_t)m * a.y_ld + co;
-                    if (!partial) {
-                        if (a.bias) v += a.bias[co];
-                        if (a.relu) v = fmaxf(v, 0.f);
-                        if (a.mask)
-                            v = (a.mask[(size_t)m * a.mask_ld + co] > 0.f) ? v * a.mask_scale
-                                                                             : 0.f;
-                        if (a.addend) v += a.addend[o];
-                    }
-                    yout[o] = v;
+                const int m = min(mbase + (r & 3) + 8 * (r >> 2), M - 1);
+                if (dense || partial) {
+                    pix[r] = m;
+                } else {
+                    const int n = m / HoWo, rem = m - n * HoWo;
+                    const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
+                    pix[r] = (n * a.out_H + oh * a.out_sh + a.out_h0) * a.out_W +
+                             ow * a.out_sw + a.out_w0;
                 }
+            }
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r];
+            if (!partial) {
+                if (a.bias) {
+                    const float b = a.bias[co];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] += b;
+                }
+                if (a.relu) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+                }
+                if (a.mask) {
+                    float mk[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mk[r] = a.mask[(size_t)pix[r] * a.mask_ld + co];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = mk[r] > 0.f ? v[r] * a.mask_scale : 0.f;
+                }
+                if (a.addend) {
+                    float ad[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ad[r] = a.addend[(size_t)pix[r] * a.y_ld + co];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] += ad[r];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mbase + (r & 3) + 8 * (r >> 2);
+                if (m < M) yout[(size_t)pix[r] * a.y_ld + co] = v[r];
             }
         }
     }
+}
+
+__device__ __forceinline__ int out_pixel(const ConvArgs& a, int m, int HoWo) {
+    const int n = m / HoWo, rem = m - n * HoWo;
+    const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
+    return (n * a.out_H + oh * a.out_sh + a.out_h0) * a.out_W + ow * a.out_sw + a.out_w0;
 }
 
 // Sum split-K partials (fixed order => deterministic) and apply the epilogue.
@@ -270,6 +311,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvArgs a, co
     const int cq = a.Cout >> 2;
     const size_t total = (size_t)M * cq;
     const size_t slab = (size_t)M * a.y_ld;
+    const int HoWo = a.Ho * a.Wo;
+    const bool dense = (a.out_sh == 1) && (a.out_sw == 1) && (a.out_H == a.Ho) &&
+                       (a.out_W == a.Wo);
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (size_t)gridDim.x * blockDim.x) {
         const int m = (int)(idx / cq);
@@ -277,22 +321,40 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvArgs a, co
         const size_t o = (size_t)m * a.y_ld + co;
         f32x4 v = *reinterpret_cast<const f32x4*>(part + o);
         for (int s = 1; s < splits; ++s) v += *reinterpret_cast<const f32x4*>(part + s * slab + o);
+        const int pix = dense ? m : out_pixel(a, m, HoWo);
+        const size_t po = (size_t)pix * a.y_ld + co;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float t = v[e];
             if (a.bias) t += a.bias[co + e];
             if (a.relu) t = fmaxf(t, 0.f);
             if (a.mask)
-                t = (a.mask[(size_t)m * a.mask_ld + co + e] > 0.f) ? t * a.mask_scale : 0.f;
-            if (a.addend) t += a.addend[o + e];
+                t = (a.mask[(size_t)pix * a.mask_ld + co + e] > 0.f) ? t * a.mask_scale : 0.f;
+            if (a.addend) t += a.addend[po + e];
             v[e] = t;
         }
-        *reinterpret_cast<f32x4*>(a.y + o) = v;
+        *reinterpret_cast<f32x4*>(a.y + po) = v;
+    }
+}
+
+// y_sub = addend_sub (or 0) for an output-parity class that no filter tap reaches
+__global__ __launch_bounds__(256) void subgrid_fill_kernel(const ConvArgs a, const int M) {
+    const int cq = a.Cout >> 2;
+    const size_t total = (size_t)M * cq;
+    const int HoWo = a.Ho * a.Wo;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(idx / cq);
+        const int co = (int)(idx - (size_t)m * cq) * 4;
+        const size_t po = (size_t)out_pixel(a, m, HoWo) * a.y_ld + co;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (a.addend) v = *reinterpret_cast<const f32x4*>(a.addend + po);
+        *reinterpret_cast<f32x4*>(a.y + po) = v;
     }
 }
 
 template <int BM, int BN, int WM, int WN, bool TU, int MODE>
-int launch_cfg(const ConvArgs& a, int M, int Ktot, int KT, hipStream_t s) {
+int launch_cfg(const ConvArgs& a, int M, int Krow, int KT, hipStream_t s) {
     constexpr int B_FLOATS = (MODE == 0) ? BN * APITCH : BK * (BN + 4);
     constexpr size_t lds = (size_t)(2 * BM * APITCH + 2 * B_FLOATS) * sizeof(float);
     static bool attr_set = false;
@@ -303,41 +365,52 @@ int launch_cfg(const ConvArgs& a, int M, int Ktot, int KT, hipStream_t s) {
         attr_set = true;
     }
     dim3 grid(cdiv(M, BM) * (a.Cout / BN), 1, a.splitk > 1 ? a.splitk : 1);
-    conv_igemm_kernel<BM, BN, WM, WN, TU, MODE><<<grid, 256, lds, s>>>(a, M, Ktot, KT);
+    conv_igemm_kernel<BM, BN, WM, WN, TU, MODE><<<grid, 256, lds, s>>>(a, M, Krow, KT);
     CILRS_LAUNCH_CHECK();
     return 0;
 }
 
-// cost model: rounds of blocks over 256 CUs x per-block MFMA work, with a mild penalty for the
-// smaller tiles' extra L2 traffic.  Returns the estimated cost (arbitrary units).
-double cfg_cost(int M, int Cout, int KT, int BM, int BN, int splitk, double penalty) {
+// cost model (cycles on one CU): MFMA work of the blocks a CU executes, a latency floor per
+// K-tile when too few blocks are co-resident to hide the load-to-use latency, a fixed
+// prologue/epilogue per block, and the split-K reduce pass.
+double cfg_cost(int M, int Cout, int KT, int BM, int BN, int splitk, int occ) {
     if (Cout % BN) return 1e30;
     const double blocks = (double)cdiv(M, BM) * (Cout / BN) * splitk;
-    const double rounds = (double)((long)((blocks + 255) / 256));
+    const double per_cu = (double)((long)((blocks + 255) / 256));      // blocks a CU runs
     const double ktiles = (double)cdiv(KT, splitk);
-    double cost = rounds * ktiles * BM * BN * penalty;
-    // fixed per-block prologue/epilogue ~ 1.5 K-tiles of work
-    cost += rounds * 1.5 * BM * BN;
-    if (splitk > 1) cost += (double)M * Cout * (splitk + 1) * 0.02 + 30000.0;
+    const double mfma = (double)BM * BN / 4.0;                          // cycles per K-tile
+    const double conc = per_cu < occ ? per_cu : occ;                    // co-resident blocks
+    const double lat = 2600.0;                                          // per K-tile, one block
+    const double t_mfma = per_cu * ktiles * mfma * (BM * BN >= 128 * 128 ? 1.12 : 1.0);
+    const double t_lat = (per_cu / conc) * ktiles * (lat + mfma * 0.25);
+    double cost = (t_mfma > t_lat ? t_mfma : t_lat) + per_cu / conc * 9000.0;
+    if (splitk > 1) cost += 4000.0 + (double)M * Cout * (splitk + 1) / 256.0 / 24.0;
     return cost;
 }
 
 struct Choice { int cfg; int splitk; };
+const int kBM[3] = {128, 128, 64};
+const int kBN[3] = {128, 64, 64};
+const int kOcc[3] = {2, 2, 4};
 
-Choice choose(int M, int Cout, int KT, bool allow_split) {
-    static const int bm[3] = {128, 128, 64};
-    static const int bn[3] = {128, 64, 64};
-    static const double pen[3] = {1.0, 1.06, 1.18};
-    static const int splits[6] = {1, 2, 3, 4, 6, 8};
-    Choice best{1, 1};
+Choice choose(int M, int Cout, int KT, bool allow_split, int force_cfg, int force_splitk) {
+    static const int splits[8] = {1, 2, 3, 4, 6, 8, 12, 16};
+    Choice best{2, 1};
     double bc = 1e30;
-    for (int c = 0; c < 3; ++c)
-        for (int si = 0; si < 6; ++si) {
-            const int sk = splits[si];
-            if (sk > 1 && (!allow_split || KT < 4 * sk)) continue;
-            const double cost = cfg_cost(M, Cout, KT, bm[c], bn[c], sk, pen[c]);
+    for (int c = 0; c < 3; ++c) {
+        if (force_cfg >= 0 && c != force_cfg) continue;
+        for (int si = 0; si < 8; ++si) {
+            int sk = splits[si];
+            if (force_splitk > 0) {
+                if (si > 0) break;
+                sk = force_splitk;
+            } else if (sk > 1 && (!allow_split || KT < 2 * sk)) {
+                continue;
+            }
+            const double cost = cfg_cost(M, Cout, KT, kBM[c], kBN[c], sk, kOcc[c]);
             if (cost < bc) { bc = cost; best = {c, sk}; }
         }
+    }
     return best;
 }
 
@@ -346,31 +419,41 @@ Choice choose(int M, int Cout, int KT, bool allow_split) {
 int launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
     ConvArgs a = a_in;
     const int M = a.N * a.Ho * a.Wo;
-    const int Ktot = a.KH * a.KW * a.Cin;
     const bool uniform = (a.Cin % BK) == 0;
-    const int KT = uniform ? a.KH * a.KW * (a.Cin / BK) : cdiv(Ktot, BK);
+    if (a.out_H == 0) {          // dense output
+        a.out_H = a.Ho; a.out_W = a.Wo; a.out_sh = a.out_sw = 1; a.out_h0 = a.out_w0 = 0;
+    }
+    if (uniform && a.ntaps == 0) {   // dense KH x KW table, forward order
+        CILRS_CHECK(a.KH * a.KW <= 16, "conv_igemm: more than 16 taps on the uniform path");
+        a.ntaps = a.KH * a.KW;
+        for (int t = 0; t < a.ntaps; ++t) {
+            a.tap_dh[t] = t / a.KW;
+            a.tap_dw[t] = t % a.KW;
+            a.tap_w[t] = (a.w_mode == 0) ? t : a.ntaps - 1 - t;      // dgrad: flipped filter
+        }
+    }
+    const int KT = uniform ? a.ntaps * (a.Cin / BK) : cdiv(a.KH * a.KW * a.Cin, BK);
+    // W_MODE 0 weight rows are addressed with the forward row pitch KH*KW*Cin
+    const int Krow = a.KH * a.KW * a.Cin;
     CILRS_CHECK(a.Cout % 64 == 0, "conv_igemm: Cout=%d must be a multiple of 64", a.Cout);
     CILRS_CHECK(a.Cin % 4 == 0 && a.x_ld % 4 == 0 && a.y_ld % 4 == 0,
                 "conv_igemm: Cin/x_ld/y_ld must be multiples of 4 (%d,%d,%d)", a.Cin, a.x_ld,
                 a.y_ld);
-    CILRS_CHECK(a.dil == 1 || a.dil == 2, "conv_igemm: dil must be 1 or 2");
-    CILRS_CHECK(uniform || (a.w_mode == 0 && a.dil == 1),
-                "conv_igemm: the generic-tap path is forward-only, undilated");
+    CILRS_CHECK(uniform || a.w_mode == 0, "conv_igemm: the generic-tap path is forward-only");
     CILRS_CHECK(a.w_mode == 0 || a.w_cin % 4 == 0, "conv_igemm: w_cin must be a multiple of 4");
     CILRS_CHECK(((uintptr_t)a.x & 15) == 0 && ((uintptr_t)a.w & 15) == 0 &&
                     ((uintptr_t)a.y & 15) == 0,
                 "conv_igemm: pointers must be 16-byte aligned");
     CILRS_CHECK(M > 0 && (size_t)a.N * a.H * a.W < (1u << 31), "conv_igemm: bad M");
+    CILRS_CHECK(a.ntaps <= 16, "conv_igemm: too many taps");
 
     // ---- tile / split-K choice ----
     const size_t slab = (size_t)M * a.y_ld;
     const bool can_split = a.scratch != nullptr && a.scratch_floats >= 2 * slab && uniform;
-    Choice ch = choose(M, a.Cout, KT, can_split);
-    if (a.force_splitk > 0) ch.splitk = a.force_splitk;
-    if (a.force_cfg >= 0) ch.cfg = a.force_cfg;
+    Choice ch = choose(M, a.Cout, KT, can_split, a.force_cfg, a.force_splitk);
     while (ch.splitk > 1 && (size_t)ch.splitk * slab > a.scratch_floats) --ch.splitk;
     CILRS_CHECK(ch.splitk == 1 || (a.scratch && uniform), "conv_igemm: split-K needs scratch");
-    CILRS_CHECK(ch.cfg >= 0 && ch.cfg < 3 && a.Cout % (ch.cfg == 0 ? 128 : 64) == 0,
+    CILRS_CHECK(ch.cfg >= 0 && ch.cfg < 3 && a.Cout % kBN[ch.cfg] == 0,
                 "conv_igemm: tile config %d does not fit Cout=%d", ch.cfg, a.Cout);
     a.splitk = ch.splitk;
     float* final_y = a.y;
@@ -379,9 +462,9 @@ int launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
     int rc = 1;
 #define CILRS_DISPATCH(BM_, BN_)                                                         \
     do {                                                                                 \
-        if (a.w_mode == 1) rc = launch_cfg<BM_, BN_, 2, 2, true, 1>(a, M, Ktot, KT, s);  \
-        else if (uniform)  rc = launch_cfg<BM_, BN_, 2, 2, true, 0>(a, M, Ktot, KT, s);  \
-        else               rc = launch_cfg<BM_, BN_, 2, 2, false, 0>(a, M, Ktot, KT, s); \
+        if (a.w_mode == 1) rc = launch_cfg<BM_, BN_, 2, 2, true, 1>(a, M, Krow, KT, s);  \
+        else if (uniform)  rc = launch_cfg<BM_, BN_, 2, 2, true, 0>(a, M, Krow, KT, s);  \
+        else               rc = launch_cfg<BM_, BN_, 2, 2, false, 0>(a, M, Krow, KT, s); \
     } while (0)
     if (ch.cfg == 0) CILRS_DISPATCH(128, 128);
     else if (ch.cfg == 1) CILRS_DISPATCH(128, 64);
@@ -397,6 +480,57 @@ int launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
         splitk_reduce_kernel<<<blocks, 256, 0, s>>>(a, part, M, a.splitk);
         CILRS_LAUNCH_CHECK();
     }
+    return 0;
+}
+
+int launch_conv_dgrad(const DgradArgs& d, hipStream_t s) {
+    CILRS_CHECK(d.stride == 1 || d.stride == 2, "dgrad: stride must be 1 or 2");
+    CILRS_CHECK(d.K * d.K <= 16, "dgrad: filter too large");
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = d.dy; a.w = d.w; a.y = d.dx; a.addend = d.addend;
+    a.mask = d.mask; a.mask_ld = d.mask_ld; a.mask_scale = d.mask_scale;
+    a.N = d.N; a.H = d.Ho; a.W = d.Wo; a.Cin = d.Cout;     // gathered tensor = dy
+    a.Cout = d.Cin;                                        // columns written = forward Cin
+    a.KH = a.KW = d.K;
+    a.x_ld = d.dy_ld; a.y_ld = d.dx_ld; a.w_mode = 1; a.w_cin = d.Cin;
+    a.scratch = d.scratch; a.scratch_floats = d.scratch_floats;
+    a.force_cfg = d.force_cfg; a.force_splitk = d.force_splitk;
+    if (d.stride == 1) {
+        a.Ho = d.H; a.Wo = d.W; a.stride = 1; a.pad = d.K - 1 - d.pad;
+        return launch_conv_igemm(a, s);           // dense table with flipped taps
+    }
+    // stride 2: dx pixel (hi, wi) = (2*oh + ph, 2*ow + pw) only sees taps kh with
+    // (ph + pad - kh) even, reading dy row oh + (ph + pad - kh)/2
+    for (int ph = 0; ph < 2; ++ph)
+        for (int pw = 0; pw < 2; ++pw) {
+            ConvArgs c = a;
+            c.Ho = (d.H - ph + 1) / 2; c.Wo = (d.W - pw + 1) / 2;
+            if (c.Ho <= 0 || c.Wo <= 0) continue;
+            c.stride = 1; c.pad = 0;
+            c.out_H = d.H; c.out_W = d.W; c.out_sh = 2; c.out_sw = 2; c.out_h0 = ph; c.out_w0 = pw;
+            int nt = 0;
+            for (int kh = 0; kh < d.K; ++kh) {
+                if ((ph + d.pad - kh) & 1) continue;
+                for (int kw = 0; kw < d.K; ++kw) {
+                    if ((pw + d.pad - kw) & 1) continue;
+                    c.tap_dh[nt] = (ph + d.pad - kh) / 2;     // exact: numerator is even
+                    c.tap_dw[nt] = (pw + d.pad - kw) / 2;
+                    c.tap_w[nt] = kh * d.K + kw;
+                    ++nt;
+                }
+            }
+            c.ntaps = nt;
+            if (nt == 0) {
+                const int M = c.N * c.Ho * c.Wo;
+                const size_t total = (size_t)M * (c.Cout / 4);
+                const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+                subgrid_fill_kernel<<<blocks, 256, 0, s>>>(c, M);
+                CILRS_LAUNCH_CHECK();
+                continue;
+            }
+            if (launch_conv_igemm(c, s)) return 1;
+        }
     return 0;
 }
 

@@ -22,9 +22,9 @@ namespace {
 constexpr int BKP = 32;   // pixels per K-tile
 
 template <int BT, bool TAP_UNIFORM>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a, const int Mpix,
-                                                         const int splits, const int tiles_ci,
-                                                         const int Ncols) {
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a, const int Mpix,
+                                                            const int splits, const int tiles_ci,
+                                                            const int Ncols) {
     // block tile BT(co) x BT(ci-columns); 4 waves as 2x2, wave tile (BT/2)^2
     constexpr int WT = BT / 2, T = WT / 32;
     constexpr int QPR = BT / 4;            // float4 quads per tile row
@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a, cons
     const int per = (KT + splits - 1) / splits;
     const int kt_begin = z * per;
     const int kt_end = min(KT, kt_begin + per);
+    const int nt = max(kt_end - kt_begin, 0);
 
     const int q = tid % QPR, rr = tid / QPR;
 
@@ -70,26 +71,47 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a, cons
     const int kh = tap / a.KW, kw = tap - kh * a.KW;
     const int HoWo = a.Ho * a.Wo;
 
-    f32x4 ra[PASSES], rb[PASSES];
-    auto load_tile = [&](int kt) {
+    // pixel cursor of each pass row for the NEXT tile to load: (n, oh, ow), advanced by BKP
+    // pixels per tile without divisions: BKP = dn*Ho*Wo + doh*Wo + dow
+    const int dn = BKP / HoWo, drem = BKP - dn * HoWo;
+    const int doh = drem / a.Wo, dow = drem - doh * a.Wo;
+    int cn[PASSES], coh[PASSES], cow[PASSES], cp[PASSES];
+#pragma unroll
+    for (int i = 0; i < PASSES; ++i) {
+        const int p = kt_begin * BKP + rr + RPP * i;
+        cp[i] = p;
+        cn[i] = p / HoWo;
+        const int rem = p - cn[i] * HoWo;
+        coh[i] = rem / a.Wo;
+        cow[i] = rem - coh[i] * a.Wo;
+    }
+    const float* dyq = a.dy + co0 + q * 4;
+
+    auto load_tile = [&](f32x4(&ra)[PASSES], f32x4(&rb)[PASSES]) {
 #pragma unroll
         for (int i = 0; i < PASSES; ++i) {
-            const int p = kt * BKP + rr + RPP * i;
             f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
-            if (p < Mpix) {
-                va = *reinterpret_cast<const f32x4*>(a.dy + (size_t)p * a.dy_ld + co0 + q * 4);
-                const int n = p / HoWo, rem = p - n * HoWo;
-                const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
-                const int h = oh * a.stride - a.pad + kh, w = ow * a.stride - a.pad + kw;
+            if (cp[i] < Mpix) {
+                va = *reinterpret_cast<const f32x4*>(dyq + (size_t)cp[i] * a.dy_ld);
+                const int h = coh[i] * a.stride - a.pad + kh, w = cow[i] * a.stride - a.pad + kw;
                 if (col_ok && h >= 0 && w >= 0 && h < a.H && w < a.W)
                     vb = *reinterpret_cast<const f32x4*>(
-                        a.x + (size_t)((n * a.H + h) * a.W + w) * a.x_ld + ci);
+                        a.x + (size_t)((cn[i] * a.H + h) * a.W + w) * a.x_ld + ci);
             }
             ra[i] = va;
             rb[i] = vb;
+            // advance the cursor by BKP pixels
+            cp[i] += BKP;
+            cow[i] += dow;
+            int c1 = cow[i] >= a.Wo;
+            cow[i] -= c1 ? a.Wo : 0;
+            coh[i] += doh + c1;
+            int c2 = coh[i] >= a.Ho;
+            coh[i] -= c2 ? a.Ho : 0;
+            cn[i] += dn + c2;
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, const f32x4(&ra)[PASSES], const f32x4(&rb)[PASSES]) {
 #pragma unroll
         for (int i = 0; i < PASSES; ++i) {
             const int row = rr + RPP * i;
@@ -106,15 +128,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a, cons
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if (kt_begin < kt_end) {
-        load_tile(kt_begin);
-        store_tile(0);
-    }
-    __syncthreads();
-    int buf = 0;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const bool more = kt + 1 < kt_end;
-        if (more) load_tile(kt + 1);
+    auto compute = [&](int buf) {
         const float* Ab = As + buf * BKP * PITCH + lh * PITCH + wm * WT + l31;
         const float* Bb = Bs + buf * BKP * PITCH + lh * PITCH + wn * WT + l31;
 #pragma unroll
@@ -131,9 +145,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a, cons
                     acc[i][j] =
                         __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
-        if (more) store_tile(buf ^ 1);
+    };
+
+    // loads run two K-tiles ahead of the MFMAs (see conv_igemm.hip)
+    f32x4 ra0[PASSES], rb0[PASSES], ra1[PASSES], rb1[PASSES];
+    if (nt > 0) load_tile(ra0, rb0);
+    if (nt > 1) load_tile(ra1, rb1);
+    if (nt > 0) store_tile(0, ra0, rb0);
+    __syncthreads();
+    for (int it = 0; it < nt; it += 2) {
+        if (it + 2 < nt) load_tile(ra0, rb0);
+        compute(0);
+        if (it + 1 < nt) store_tile(1, ra1, rb1);
         __syncthreads();
-        buf ^= 1;
+        if (it + 1 >= nt) break;
+        if (it + 3 < nt) load_tile(ra1, rb1);
+        compute(1);
+        if (it + 2 < nt) store_tile(0, ra0, rb0);
+        __syncthreads();
     }
 
     // slab[z][co][col]  (col = tap*Cin + ci, OHWI order)

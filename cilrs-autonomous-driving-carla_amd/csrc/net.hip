@@ -220,6 +220,7 @@ struct cilrs_net {
     size_t gmax;
     size_t bn_partial, bn_coef, slabs, slabs_floats, ksplit, ksplit_floats, status_b;
     size_t ws_bytes;
+    float* ws_base = nullptr;             // workspace of the current call (set by every entry)
     bool trained_fwd = false;
     float last_dropout = 0.f;
     Prof prof;
@@ -263,7 +264,7 @@ int conv_fwd(cilrs_net* net, const ConvT& c, const ConvG& g, const float* x, int
     a.x = x; a.w = w; a.y = y;
     a.N = net->B; a.H = g.H; a.W = g.W; a.Cin = x_cin;
     a.Ho = g.Ho; a.Wo = g.Wo; a.Cout = c.cout;
-    a.KH = a.KW = c.k; a.stride = c.stride; a.pad = c.pad; a.dil = 1;
+    a.KH = a.KW = c.k; a.stride = c.stride; a.pad = c.pad;
     a.x_ld = x_cin; a.y_ld = c.cout; a.w_mode = 0; a.w_cin = x_cin;
     a.scratch = ws + net->ksplit; a.scratch_floats = net->ksplit_floats;
     a.force_cfg = -1;
@@ -278,20 +279,19 @@ int conv_fwd(cilrs_net* net, const ConvT& c, const ConvG& g, const float* x, int
 // dx[B,H,W,cin] (+= addend) from dy[B,Ho,Wo,cout]
 int conv_dgrad(cilrs_net* net, const ConvT& c, const ConvG& g, const float* dy, const float* w,
                float* dx, const float* addend, float* ws, hipStream_t s) {
-    ConvArgs a;
+    DgradArgs a;
     memset(&a, 0, sizeof(a));
-    a.x = dy; a.w = w; a.y = dx; a.addend = addend;
-    a.N = net->B; a.H = g.Ho; a.W = g.Wo; a.Cin = c.cout;
-    a.Ho = g.H; a.Wo = g.W; a.Cout = c.cin;
-    a.KH = a.KW = c.k; a.stride = 1; a.pad = c.k - 1 - c.pad; a.dil = c.stride;
-    a.x_ld = c.cout; a.y_ld = c.cin; a.w_mode = 1; a.w_cin = c.cin;
+    a.dy = dy; a.w = w; a.dx = dx; a.addend = addend;
+    a.N = net->B; a.H = g.H; a.W = g.W; a.Cin = c.cin;
+    a.Ho = g.Ho; a.Wo = g.Wo; a.Cout = c.cout; a.K = c.k; a.stride = c.stride; a.pad = c.pad;
+    a.dy_ld = c.cout; a.dx_ld = c.cin;
     a.scratch = ws + net->ksplit; a.scratch_floats = net->ksplit_floats;
     a.force_cfg = -1;
     const double flops = 2.0 * g.M * c.cout * c.k * c.k * c.cin;
     const double bytes = 4.0 * ((double)net->B * g.H * g.W * c.cin + (double)g.M * c.cout +
                                 (double)c.cout * c.k * c.k * c.cin);
     RUN(net, std::string("conv_dgrad.") + kGroupName[c.group], flops, bytes, s,
-        launch_conv_igemm(a, s));
+        launch_conv_dgrad(a, s));
     return 0;
 }
 
@@ -320,8 +320,9 @@ int lin_fwd(cilrs_net* net, const LinT& l, const float* P, const float* x, int x
     memset(&a, 0, sizeof(a));
     a.x = x; a.w = P + l.w; a.y = y; a.bias = P + l.b;
     a.N = net->B; a.H = 1; a.W = 1; a.Cin = l.in; a.Ho = 1; a.Wo = 1; a.Cout = l.out;
-    a.KH = a.KW = 1; a.stride = 1; a.pad = 0; a.dil = 1;
+    a.KH = a.KW = 1; a.stride = 1; a.pad = 0;
     a.x_ld = x_ld; a.y_ld = y_ld; a.w_mode = 0; a.w_cin = l.in; a.relu = relu;
+    a.scratch = net->ws_base + net->ksplit; a.scratch_floats = net->ksplit_floats;
     a.force_cfg = -1;
     RUN(net, "heads_fwd", 2.0 * net->B * l.in * l.out, 4.0 * l.in * l.out, s,
         launch_conv_igemm(a, s));
@@ -332,16 +333,17 @@ int lin_fwd(cilrs_net* net, const LinT& l, const float* P, const float* x, int x
 int lin_dgrad(cilrs_net* net, const LinT& l, const float* P, const float* dy, int dy_ld,
               float* dx, int dx_ld, const float* act, int act_ld, float act_scale,
               const float* addend, hipStream_t s) {
-    ConvArgs a;
+    DgradArgs a;
     memset(&a, 0, sizeof(a));
-    a.x = dy; a.w = P + l.w; a.y = dx; a.addend = addend; a.mask = act; a.mask_ld = act_ld;
-    a.mask_scale = act_scale;
-    a.N = net->B; a.H = 1; a.W = 1; a.Cin = l.out; a.Ho = 1; a.Wo = 1; a.Cout = l.in;
-    a.KH = a.KW = 1; a.stride = 1; a.pad = 0; a.dil = 1;
-    a.x_ld = dy_ld; a.y_ld = dx_ld; a.w_mode = 1; a.w_cin = l.in;
+    a.dy = dy; a.w = P + l.w; a.dx = dx; a.addend = addend;
+    a.mask = act; a.mask_ld = act_ld; a.mask_scale = act_scale;
+    a.N = net->B; a.H = 1; a.W = 1; a.Cin = l.in; a.Ho = 1; a.Wo = 1; a.Cout = l.out;
+    a.K = 1; a.stride = 1; a.pad = 0;
+    a.dy_ld = dy_ld; a.dx_ld = dx_ld;
+    a.scratch = net->ws_base + net->ksplit; a.scratch_floats = net->ksplit_floats;
     a.force_cfg = -1;
     RUN(net, "heads_bwd", 2.0 * net->B * l.in * l.out, 4.0 * l.in * l.out, s,
-        launch_conv_igemm(a, s));
+        launch_conv_dgrad(a, s));
     return 0;
 }
 
@@ -541,6 +543,7 @@ static int forward_from_x4(cilrs_net* net, const cilrs_buffers* bufs, const floa
                            float* controls, float* pred_speed, hipStream_t s) {
     const Arch& A = arch();
     float* ws = reinterpret_cast<float*>(bufs->workspace);
+    net->ws_base = ws;
     const float* P = bufs->params;
     float* R = bufs->bn_running;
     const int B = net->B;
@@ -704,6 +707,7 @@ int cilrs_net_backward(cilrs_net* net, const cilrs_buffers* bufs, const float* d
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const Arch& A = arch();
     float* ws = reinterpret_cast<float*>(bufs->workspace);
+    net->ws_base = ws;
     const float* P = bufs->params;
     float* Gp = bufs->grads;
     const int B = net->B;
@@ -929,7 +933,7 @@ int cilrs_conv2d_fwd(const float* x, const float* w, float* y, int N, int H, int
     a.x = x; a.w = w; a.y = y;
     a.N = N; a.H = H; a.W = W; a.Cin = Cin;
     a.Ho = (H + 2 * pad - KH) / stride + 1; a.Wo = (W + 2 * pad - KW) / stride + 1; a.Cout = Cout;
-    a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.dil = 1;
+    a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
     a.x_ld = Cin; a.y_ld = Cout; a.w_mode = 0; a.w_cin = Cin;
     a.scratch = scratch; a.scratch_floats = scratch_floats;
     a.force_cfg = force_cfg; a.force_splitk = force_splitk;
@@ -941,17 +945,16 @@ int cilrs_conv2d_dgrad(const float* dy, const float* w, float* dx, const float* 
                        int force_cfg, int force_splitk, float* scratch, size_t scratch_floats,
                        void* stream) {
     CILRS_CHECK(KH == KW, "dgrad: square kernels only");
-    ConvArgs a;
+    DgradArgs a;
     memset(&a, 0, sizeof(a));
-    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
-    a.x = dy; a.w = w; a.y = dx; a.addend = addend;
-    a.N = N; a.H = Ho; a.W = Wo; a.Cin = Cout;
-    a.Ho = H; a.Wo = W; a.Cout = Cin;
-    a.KH = KH; a.KW = KW; a.stride = 1; a.pad = KH - 1 - pad; a.dil = stride;
-    a.x_ld = Cout; a.y_ld = Cin; a.w_mode = 1; a.w_cin = Cin;
+    a.dy = dy; a.w = w; a.dx = dx; a.addend = addend;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin;
+    a.Ho = (H + 2 * pad - KH) / stride + 1; a.Wo = (W + 2 * pad - KW) / stride + 1;
+    a.Cout = Cout; a.K = KH; a.stride = stride; a.pad = pad;
+    a.dy_ld = Cout; a.dx_ld = Cin;
     a.scratch = scratch; a.scratch_floats = scratch_floats;
     a.force_cfg = force_cfg; a.force_splitk = force_splitk;
-    return launch_conv_igemm(a, reinterpret_cast<hipStream_t>(stream));
+    return launch_conv_dgrad(a, reinterpret_cast<hipStream_t>(stream));
 }
 
 static WgradArgs make_wgrad(const float* x, const float* dy, float* dw, float* scratch, int N,
