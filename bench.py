@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--config", default="A", choices=["A", "B"])
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-infer", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -168,7 +169,7 @@ def main():
     }
 
     log(f"{value:.1f} frames/s, {wall / args.steps * 1e3:.3f} ms/step")
-    if world == 1:
+    if world == 1 and args.profile_steps > 0:
         # ---- per-kernel hipEvent timing on the launch stream (extra steps, same step fn) ----
         pl = trainer.eng.plan(args.batch, 88, 200)
         pl.profile_reset()
@@ -201,6 +202,16 @@ def main():
             "flops_per_launch": round(dom["flops"] / max(dom["calls"], 1), 1),
             "share_of_step": round(dom["ms"] / max(total_ms, 1e-9), 4),
         }
+        # HBM traffic per launch of that kernel family: rocprofv3 PMC passes (FETCH_SIZE doubled,
+        # WRITE_SIZE as is -- MI355X_MICROARCH.md, HBM section), measured by tools/pmc_traffic.sh
+        # on this same command and committed under profiles/
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            key = "igemm" if dom is igemm else "wgrad"
+            if key in tj:
+                out["roofline"]["traffic"] = tj[key]["bytes_per_launch"]
+                out["roofline"]["traffic_source"] = tj.get("source", "profiles/traffic.json")
         out["kernels"] = {
             f: {"calls_per_step": a["calls"] // max(args.profile_steps, 1),
                 "ms_per_step": round(a["ms"] / args.profile_steps, 4),
@@ -213,6 +224,7 @@ def main():
             for l, r in sorted(table.items()) if l.startswith("conv_")}
 
         log("per-kernel profile done; inference latency")
+    if world == 1 and not args.no_infer:
         # ---- single-frame inference latency (predict_controls path) ----
         from cilrs_mi355.predict import Predictor
         pr = Predictor(model)
@@ -226,9 +238,22 @@ def main():
             lat.append((time.perf_counter() - t1) * 1e3)
         lat.sort()
         out["infer_ms"] = round(lat[len(lat) // 2], 4)
+        # device-side breakdown of one B=1 forward (eager launches, hipEvent per kernel)
+        pl1 = trainer.eng.plan(1, 88, 200)
+        pl1.profile_reset()
+        pl1.profile(True)
+        pr.use_graph = False
+        for _ in range(10):
+            pr.predict_controls(frame, 25.0, 0)
+        torch.cuda.synchronize(dev)
+        t1 = pl1.profile_table()
+        pl1.profile(False)
+        pr.use_graph = True
+        out["infer_device_us"] = {k: round(v["ms"] / 10 * 1e3, 1)
+                                  for k, v in sorted(t1.items(), key=lambda kv: -kv[1]["ms"])}
+        out["infer_device_us"]["total"] = round(sum(v["ms"] for v in t1.values()) / 10 * 1e3, 1)
         model.train()
 
-        log(f"infer {out['infer_ms']} ms; cpu baseline" )
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.batch)
     print(json.dumps(out))

@@ -45,6 +45,7 @@ SIGNATURES = {
     "cilrs_net_forward": (i32, [vp, C.POINTER(Buffers), vp, C.c_long, C.c_long, C.c_long,
                                 C.c_long, vp, vp, i32, f32, u64, vp, vp, vp]),
     "cilrs_net_forward_u8": (i32, [vp, C.POINTER(Buffers), vp, vp, vp, vp, vp, vp]),
+    "cilrs_net_forward_u8_graph": (i32, [vp, C.POINTER(Buffers), vp, vp, vp, vp, vp, vp]),
     "cilrs_loss_fwd_bwd": (i32, [vp, vp, vp, vp, i32, i32, c_float_p, f32, vp, vp, vp, vp]),
     "cilrs_net_backward": (i32, [vp, C.POINTER(Buffers), vp, vp, i32, i32, vp]),
     "cilrs_segment_range": (i32, [i32, C.POINTER(sz), C.POINTER(sz)]),

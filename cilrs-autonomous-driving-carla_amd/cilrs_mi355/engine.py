@@ -214,19 +214,24 @@ class Engine:
             pl.generation += 1
         return controls, pred_speed, pl
 
-    def run_forward_u8(self, frames_u8, speed, command):
-        """uint8 RGB HWC frames [B,H,W,3] -> eval forward with fused preprocessing."""
+    def run_forward_u8(self, frames_u8, speed, command, out=None, graph=False):
+        """uint8 RGB HWC frames [B,H,W,3] -> eval forward with fused preprocessing.  With
+        graph=True the launch sequence is replayed from a cached hipGraph (all tensors must keep
+        their addresses; the current stream must not be the default stream)."""
         if frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4 or frames_u8.size(3) != 3:
             raise RuntimeError("frames must be uint8 [B,H,W,3]")
         b = frames_u8.size(0)
         pl = self.plan(b, frames_u8.size(1), frames_u8.size(2))
         frames_u8 = frames_u8.contiguous()
-        controls = torch.empty(b, 3, dtype=torch.float32, device=self.device)
-        pred_speed = torch.empty(b, dtype=torch.float32, device=self.device)
-        L.check(L.lib().cilrs_net_forward_u8(
-            pl.handle, C.byref(self.bufs[(pl.batch, pl.h, pl.w)]), L.ptr(frames_u8),
-            L.ptr(speed.contiguous()), L.ptr(command.contiguous()), L.ptr(controls),
-            L.ptr(pred_speed), self._stream()))
+        if out is None:
+            controls = torch.empty(b, 3, dtype=torch.float32, device=self.device)
+            pred_speed = torch.empty(b, dtype=torch.float32, device=self.device)
+        else:
+            controls, pred_speed = out
+        fn = L.lib().cilrs_net_forward_u8_graph if graph else L.lib().cilrs_net_forward_u8
+        L.check(fn(pl.handle, C.byref(self.bufs[(pl.batch, pl.h, pl.w)]), L.ptr(frames_u8),
+                   L.ptr(speed.contiguous()), L.ptr(command.contiguous()), L.ptr(controls),
+                   L.ptr(pred_speed), self._stream()))
         return controls, pred_speed
 
     def run_backward(self, pl, dcontrols, dpred_speed, seg_begin=0, seg_end=6):

@@ -21,11 +21,16 @@ class Predictor:
     """Holds pinned staging buffers so a 20 Hz control loop does one H2D and one D2H copy per
     tick (the reference does four ``.item()`` syncs, :918-920)."""
 
-    def __init__(self, model, batch=1, height=IMG_HEIGHT, width=IMG_WIDTH):
+    def __init__(self, model, batch=1, height=IMG_HEIGHT, width=IMG_WIDTH, use_graph=True):
         self.model = model.eval()
         self.eng = model.engine()
         dev = self.eng.device
         self.batch = batch
+        self.use_graph = use_graph
+        self.stream = torch.cuda.Stream(device=dev)      # hipGraph capture needs its own stream
+        self.ctrl_dev = torch.empty(batch, 3, dtype=torch.float32, device=dev)
+        self.spd_out_dev = torch.empty(batch, dtype=torch.float32, device=dev)
+        self.out_dev = torch.empty(batch, 4, dtype=torch.float32, device=dev)
         self.frames_host = torch.empty(batch, height, width, 3, dtype=torch.uint8).pin_memory()
         self.frames_dev = torch.empty(batch, height, width, 3, dtype=torch.uint8, device=dev)
         self.speed_host = torch.empty(batch, dtype=torch.float32).pin_memory()
@@ -39,20 +44,25 @@ class Predictor:
         """frames uint8 [B,88,200,3] RGB, km/h, command idx -> np.float32 [B,4] =
         (steer, throttle, brake, speed_kmh)."""
         if self.model.engine() is not self.eng:
-            self.__init__(self.model, self.batch, self.frames_host.size(1), self.frames_host.size(2))
+            self.__init__(self.model, self.batch, self.frames_host.size(1),
+                          self.frames_host.size(2), self.use_graph)
+        if self.model.training:
+            self.model.eval()
         self.frames_host.copy_(torch.as_tensor(frames_u8))
         sp = np.minimum(np.asarray(speeds_kmh, dtype=np.float32) / np.float32(SPEED_NORM_FACTOR),
                         np.float32(1.0))
         self.speed_host.copy_(torch.from_numpy(sp))
         self.cmd_host.copy_(torch.as_tensor(commands, dtype=torch.int64))
-        self.frames_dev.copy_(self.frames_host, non_blocking=True)
-        self.speed_dev.copy_(self.speed_host, non_blocking=True)
-        self.cmd_dev.copy_(self.cmd_host, non_blocking=True)
-        controls, pred_speed = self.eng.run_forward_u8(self.frames_dev, self.speed_dev,
-                                                       self.cmd_dev)
-        out = torch.cat([controls, (pred_speed * SPEED_NORM_FACTOR).unsqueeze(1)], dim=1)
-        self.out_host.copy_(out, non_blocking=True)
-        torch.cuda.current_stream(self.eng.device).synchronize()
+        with torch.cuda.stream(self.stream):
+            self.frames_dev.copy_(self.frames_host, non_blocking=True)
+            self.speed_dev.copy_(self.speed_host, non_blocking=True)
+            self.cmd_dev.copy_(self.cmd_host, non_blocking=True)
+            self.eng.run_forward_u8(self.frames_dev, self.speed_dev, self.cmd_dev,
+                                    out=(self.ctrl_dev, self.spd_out_dev), graph=self.use_graph)
+            self.out_dev[:, :3].copy_(self.ctrl_dev)
+            torch.mul(self.spd_out_dev, SPEED_NORM_FACTOR, out=self.out_dev[:, 3])
+            self.out_host.copy_(self.out_dev, non_blocking=True)
+            self.stream.synchronize()
         return self.out_host.numpy().copy()
 
     def predict_controls(self, image_rgb_u8, speed_kmh, command_idx):

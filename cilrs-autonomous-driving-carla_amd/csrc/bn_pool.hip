@@ -97,12 +97,13 @@ __global__ __launch_bounds__(256) void bn_colreduce_kernel(
 // then a fixed-order LDS combine (deterministic).  Returns the two sums to threads g == 0.
 __device__ __forceinline__ bool partial_sums(const float* __restrict__ partial, const int nblk,
                                              const int C, int& c, double& s1, double& s2) {
-    __shared__ double red[2][8][32];
+    __shared__ double red[2][32][32];
     const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int ng = blockDim.x >> 5;           // 8 or 32 partial-groups
     c = blockIdx.x * 32 + cl;
     double a1 = 0.0, a2 = 0.0;
     if (c < C)
-        for (int b = g; b < nblk; b += 8) {
+        for (int b = g; b < nblk; b += ng) {
             a1 += (double)partial[(size_t)b * 2 * C + c];
             a2 += (double)partial[(size_t)b * 2 * C + C + c];
         }
@@ -111,13 +112,12 @@ __device__ __forceinline__ bool partial_sums(const float* __restrict__ partial, 
     __syncthreads();
     if (g != 0 || c >= C) return false;
     s1 = 0.0; s2 = 0.0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { s1 += red[0][k][cl]; s2 += red[1][k][cl]; }
+    for (int k = 0; k < ng; ++k) { s1 += red[0][k][cl]; s2 += red[1][k][cl]; }
     return true;
 }
 
 // stats layout (floats): [0,C) mean | [C,2C) rstd | [2C,3C) w = gamma*rstd | [3C,4C) b = beta-mean*w
-__global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(
+__global__ __launch_bounds__(1024) void bn_fwd_finalize_kernel(
     const float* __restrict__ partial, const int nblk, const int M, const int C,
     const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
     float* running_var, long long* nbt, const float momentum, const float eps,
@@ -156,6 +156,29 @@ __global__ void bn_eval_stats_kernel(const float* __restrict__ gamma,
     stats[C + c] = rstd;
     stats[2 * C + c] = w;
     stats[3 * C + c] = beta[c] - running_mean[c] * w;
+}
+
+// every BatchNorm layer's eval-mode scale/shift in one launch: block b = layer b
+__global__ __launch_bounds__(256) void bn_eval_stats_all_kernel(const BnEvalTable t,
+                                                                const float* __restrict__ params,
+                                                                const float* __restrict__ running,
+                                                                float* __restrict__ ws,
+                                                                const float eps) {
+    const int l = blockIdx.x;
+    const int C = t.C[l];
+    const float* gamma = params + t.gamma[l];
+    const float* beta = params + t.beta[l];
+    const float* rm = running + t.rm[l];
+    const float* rv = running + t.rv[l];
+    float* stats = ws + t.stats[l];
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float rstd = 1.0f / sqrtf(rv[c] + eps);
+        const float w = gamma[c] * rstd;
+        stats[c] = rm[c];
+        stats[C + c] = rstd;
+        stats[2 * C + c] = w;
+        stats[3 * C + c] = beta[c] - rm[c] * w;
+    }
 }
 
 // z = relu?( y*w + b (+ residual) )
@@ -377,13 +400,17 @@ static int check_c(int C) {
 int launch_bn_train_fwd(const float* y, int M, int C, const float* gamma, const float* beta,
                         float* running_mean, float* running_var, long long* nbt, float momentum,
                         float eps, const float* residual, int relu, float* stats, float* partial,
-                        float* z, hipStream_t s) {
+                        float* z, int pre_nblk, hipStream_t s) {
     if (check_c(C)) return 1;
-    const ColPlan p = col_plan(M, C);
-    bn_colreduce_kernel<0><<<p.nblk, 256, 0, s>>>(y, nullptr, nullptr, nullptr, partial, M, C, 0,
-                                                  p.rows_per_block);
-    CILRS_LAUNCH_CHECK();
-    bn_fwd_finalize_kernel<<<cdiv(C, 32), 256, 0, s>>>(partial, p.nblk, M, C, gamma, beta,
+    int nblk = pre_nblk;
+    if (nblk <= 0) {
+        const ColPlan p = col_plan(M, C);
+        bn_colreduce_kernel<0><<<p.nblk, 256, 0, s>>>(y, nullptr, nullptr, nullptr, partial, M, C,
+                                                      0, p.rows_per_block);
+        CILRS_LAUNCH_CHECK();
+        nblk = p.nblk;
+    }
+    bn_fwd_finalize_kernel<<<cdiv(C, 32), 1024, 0, s>>>(partial, nblk, M, C, gamma, beta,
                                                         running_mean, running_var, nbt, momentum,
                                                         eps, stats);
     CILRS_LAUNCH_CHECK();
@@ -392,6 +419,13 @@ int launch_bn_train_fwd(const float* y, int M, int C, const float* gamma, const 
         bn_apply_kernel<<<grid_for(total4), 256, 0, s>>>(y, stats, residual, z, total4, C, relu);
         CILRS_LAUNCH_CHECK();
     }
+    return 0;
+}
+
+int launch_bn_eval_stats_all(const BnEvalTable& t, const float* params, const float* bn_running,
+                             float* ws, float eps, hipStream_t s) {
+    bn_eval_stats_all_kernel<<<t.n, 256, 0, s>>>(t, params, bn_running, ws, eps);
+    CILRS_LAUNCH_CHECK();
     return 0;
 }
 

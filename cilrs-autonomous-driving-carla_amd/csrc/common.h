@@ -59,6 +59,9 @@ struct ConvArgs {
     float* y;              // [N][out_H][out_W] pixels, y_ld floats apart, Cout columns written
     const float* addend;   // optional, y's layout: y = acc + addend (may alias y)
     const float* bias;     // optional [Cout]
+    const float* ch_scale; // optional [Cout] per-channel affine applied first: y = acc*scale+shift
+    const float* ch_shift; //   (eval-mode BatchNorm folded into the conv epilogue)
+    int relu_post;         // ReLU after the addend (BasicBlock: relu(bn(conv) + identity))
     const float* mask;     // optional, pixel-indexed like y, mask_ld apart:
                            //   y = (mask > 0) ? y * mask_scale : 0
     int N, H, W, Cin;      // geometry of the tensor the A-gather reads
@@ -77,6 +80,9 @@ struct ConvArgs {
     // forward tap tap_w.  ntaps == 0 on entry => launcher fills the dense KHxKW table.
     int ntaps;
     int tap_dh[16], tap_dw[16], tap_w[16];
+    float* bn_partial;     // optional: per-M-tile column sums / sums of squares of the raw output,
+                           // [tile][2][Cout] (BatchNorm batch statistics fused into the conv)
+    int* bn_nblk;          // host out: tiles written (0 = not fused, e.g. split-K was chosen)
     float* scratch;        // optional split-K scratch (>= 2*M*y_ld floats to be considered)
     size_t scratch_floats;
     int force_cfg;         // -1 auto; 0: 128x128, 1: 128x64, 2: 64x64 block tile (tests/tuning)
@@ -115,10 +121,21 @@ int launch_conv_wgrad(const WgradArgs& a, hipStream_t s);
 // ---- BatchNorm / pooling (bn_pool.hip) --------------------------------------------------------
 // stats: 4*C floats (mean | rstd | w | b); coef: 3*C floats; partial: bn_partial_floats(C) floats
 size_t bn_partial_floats(int C);
+// pre_nblk > 0: `partial` already holds pre_nblk per-tile partial sums (fused into the conv)
 int launch_bn_train_fwd(const float* y, int M, int C, const float* gamma, const float* beta,
                         float* running_mean, float* running_var, long long* nbt, float momentum,
                         float eps, const float* residual, int relu, float* stats, float* partial,
-                        float* z, hipStream_t s);
+                        float* z, int pre_nblk, hipStream_t s);
+// eval-mode scale/shift of up to 40 BatchNorm layers in one launch (offsets in floats)
+struct BnEvalTable {
+    int n;
+    int C[40];
+    unsigned gamma[40], beta[40];      // into the parameter arena
+    unsigned rm[40], rv[40];           // into the BN buffer arena
+    unsigned stats[40];                // into the workspace (4*C floats: mean|rstd|w|b)
+};
+int launch_bn_eval_stats_all(const BnEvalTable& t, const float* params, const float* bn_running,
+                             float* ws, float eps, hipStream_t s);
 int launch_bn_eval_fwd(const float* y, int M, int C, const float* gamma, const float* beta,
                        const float* running_mean, const float* running_var, float eps,
                        const float* residual, int relu, float* stats, float* z, hipStream_t s);
@@ -151,6 +168,8 @@ int launch_colsum(const float* dy, float* db, int B, int out, int dy_ld, int acc
                   hipStream_t s);
 int launch_relu_mask(float* d, const float* act, int B, int cols, int d_ld, int act_ld,
                      float scale, hipStream_t s);
+int launch_sum_parts(const float* p0, const float* p1, const float* p2, const float* p3,
+                     const float* p4, float* out, int B, int cols, int cols4, hipStream_t s);
 int launch_dropout(float* a, int B, int cols, int ld, float p, unsigned long long seed,
                    unsigned long long stream, hipStream_t s);
 int launch_branch_gather(const float* all_out, const long long* cmd, float* controls, int B,

@@ -236,6 +236,42 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a, co
         __syncthreads();
     }
 
+    // ---- fused BatchNorm statistics: per-channel sum / sum of squares of this M-tile's rows
+    // (rows >= M are exact zeros).  Fixed summation order => deterministic.
+    if (a.bn_partial != nullptr && a.splitk <= 1) {
+        float* red = smem;                       // [WM][BN][2]; the K loop ended on a barrier
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc[i][j][r];
+                    s1 += v;
+                    s2 = fmaf(v, v, s2);
+                }
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 32);
+            if (lh == 0) {
+                red[(wm * BN + wn * WTN + j * 32 + l31) * 2] = s1;
+                red[(wm * BN + wn * WTN + j * 32 + l31) * 2 + 1] = s2;
+            }
+        }
+        __syncthreads();
+        if (tid < BN) {
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) {
+                t1 += red[(w * BN + tid) * 2];
+                t2 += red[(w * BN + tid) * 2 + 1];
+            }
+            const size_t mt = (size_t)(logical / tilesN);
+            a.bn_partial[mt * 2 * a.Cout + n0 + tid] = t1;
+            a.bn_partial[mt * 2 * a.Cout + a.Cout + n0 + tid] = t2;
+        }
+    }
+
     // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     // Optional operands are fetched as 16 independent loads per tile (clamped row, no per-element
     // branch) so their latency overlaps instead of serialising.
@@ -266,6 +302,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a, co
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r];
             if (!partial) {
+                if (a.ch_scale) {
+                    const float sc = a.ch_scale[co], sh = a.ch_shift[co];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = v[r] * sc + sh;
+                }
                 if (a.bias) {
                     const float b = a.bias[co];
 #pragma unroll
@@ -288,6 +329,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a, co
                     for (int r = 0; r < 16; ++r) ad[r] = a.addend[(size_t)pix[r] * a.y_ld + co];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) v[r] += ad[r];
+                }
+                if (a.relu_post) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
                 }
             }
 #pragma unroll
@@ -326,11 +371,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvArgs a, co
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float t = v[e];
+            if (a.ch_scale) t = t * a.ch_scale[co + e] + a.ch_shift[co + e];
             if (a.bias) t += a.bias[co + e];
             if (a.relu) t = fmaxf(t, 0.f);
             if (a.mask)
                 t = (a.mask[(size_t)pix * a.mask_ld + co + e] > 0.f) ? t * a.mask_scale : 0.f;
             if (a.addend) t += a.addend[po + e];
+            if (a.relu_post) t = fmaxf(t, 0.f);
             v[e] = t;
         }
         *reinterpret_cast<f32x4*>(a.y + po) = v;
@@ -456,6 +503,7 @@ int launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
     CILRS_CHECK(ch.cfg >= 0 && ch.cfg < 3 && a.Cout % kBN[ch.cfg] == 0,
                 "conv_igemm: tile config %d does not fit Cout=%d", ch.cfg, a.Cout);
     a.splitk = ch.splitk;
+    if (a_in.bn_nblk) *a_in.bn_nblk = (a.bn_partial && a.splitk == 1) ? cdiv(M, kBM[ch.cfg]) : 0;
     float* final_y = a.y;
     if (a.splitk > 1) a.y = a.scratch;
 

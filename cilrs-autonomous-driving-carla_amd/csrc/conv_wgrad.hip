@@ -15,6 +15,8 @@
 // (deterministic, no float atomics).
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace cilrs {
 
 namespace {
@@ -128,22 +130,29 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a, c
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // T == 2: the two 32-wide MFMA tiles of a wave take the EVEN / ODD channels of its 64, so one
+    // ds_read_b64 per operand feeds four MFMAs (tile t, row i <-> channel 2i + t)
     auto compute = [&](int buf) {
-        const float* Ab = As + buf * BKP * PITCH + lh * PITCH + wm * WT + l31;
-        const float* Bb = Bs + buf * BKP * PITCH + lh * PITCH + wn * WT + l31;
+        if constexpr (T == 2) {
+            const float* Ab = As + buf * BKP * PITCH + lh * PITCH + wm * WT + 2 * l31;
+            const float* Bb = Bs + buf * BKP * PITCH + lh * PITCH + wn * WT + 2 * l31;
 #pragma unroll
-        for (int s = 0; s < BKP / 2; ++s) {
-            float af[T], bf[T];
+            for (int s = 0; s < BKP / 2; ++s) {
+                const float2 av = *reinterpret_cast<const float2*>(Ab + 2 * s * PITCH);
+                const float2 bv = *reinterpret_cast<const float2*>(Bb + 2 * s * PITCH);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.y, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.x, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[1][1], 0, 0, 0);
+            }
+        } else {
+            const float* Ab = As + buf * BKP * PITCH + lh * PITCH + wm * WT + l31;
+            const float* Bb = Bs + buf * BKP * PITCH + lh * PITCH + wn * WT + l31;
 #pragma unroll
-            for (int i = 0; i < T; ++i) af[i] = Ab[2 * s * PITCH + i * 32];
-#pragma unroll
-            for (int j = 0; j < T; ++j) bf[j] = Bb[2 * s * PITCH + j * 32];
-#pragma unroll
-            for (int i = 0; i < T; ++i)
-#pragma unroll
-                for (int j = 0; j < T; ++j)
-                    acc[i][j] =
-                        __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+            for (int s = 0; s < BKP / 2; ++s) {
+                const float af = Ab[2 * s * PITCH], bf = Bb[2 * s * PITCH];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[0][0], 0, 0, 0);
+            }
         }
     };
 
@@ -167,18 +176,28 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a, c
 
     // slab[z][co][col]  (col = tap*Cin + ci, OHWI order)
     float* out = a.slabs + (size_t)z * a.Cout * Ncols;
+    if constexpr (T == 2) {
+        const int col = col0 + wn * WT + 2 * l31;
 #pragma unroll
-    for (int i = 0; i < T; ++i)
-#pragma unroll
-        for (int j = 0; j < T; ++j) {
-            const int col = col0 + wn * WT + j * 32 + l31;
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int co = co0 + wm * WT + i * 32 + row;
-                if (col < Ncols) out[(size_t)co * Ncols + col] = acc[i][j][r];
+                const int co = co0 + wm * WT + 2 * row + i;
+                float2 v;
+                v.x = acc[i][0][r];
+                v.y = acc[i][1][r];
+                *reinterpret_cast<float2*>(out + (size_t)co * Ncols + col) = v;
             }
+    } else {
+        const int col = col0 + wn * WT + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int co = co0 + wm * WT + row;
+            if (col < Ncols) out[(size_t)co * Ncols + col] = acc[0][0][r];
         }
+    }
 }
 
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slabs, float* dw,
@@ -205,6 +224,9 @@ WPlan plan(const WgradArgs& a) {
     p.ncols = taps * a.Cin;
     p.uniform = (a.Cin % 64) == 0;
     p.bt = (p.uniform && a.Cin % 128 == 0 && a.Cout % 128 == 0) ? 128 : 64;
+    static const int env_bt = getenv("CILRS_WGRAD_BT") ? atoi(getenv("CILRS_WGRAD_BT")) : 0;
+    static const int env_target = getenv("CILRS_WGRAD_TARGET") ? atoi(getenv("CILRS_WGRAD_TARGET")) : 0;
+    if (env_bt == 64) p.bt = 64;
     if (p.uniform) {
         p.tiles_ci = a.Cin / p.bt;
         p.ntiles = taps * p.tiles_ci;
@@ -214,7 +236,9 @@ WPlan plan(const WgradArgs& a) {
     }
     const int tiles = p.ntiles * (a.Cout / p.bt);
     const int KT = cdiv(Mpix, BKP);
-    int splits = cdiv(768, tiles);
+    int target = 768;      // measured best over 256..1536 on the trunk shapes (tools/wgrad_sweep.sh)
+    if (env_target > 0) target = env_target;
+    int splits = cdiv(target, tiles);
     const int max_splits = KT / 8 > 0 ? KT / 8 : 1;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;

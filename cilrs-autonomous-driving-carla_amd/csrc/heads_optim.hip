@@ -145,6 +145,22 @@ __global__ __launch_bounds__(256) void relu_mask_kernel(float* __restrict__ d,
     d[o] = act[(size_t)b * act_ld + c] > 0.f ? d[o] * scale : 0.f;
 }
 
+// out[b][c] = p0+p1+p2+p3 (+ p4 for c < cols4) -- fixed order, deterministic
+__global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict__ p0,
+                                                        const float* __restrict__ p1,
+                                                        const float* __restrict__ p2,
+                                                        const float* __restrict__ p3,
+                                                        const float* __restrict__ p4,
+                                                        float* __restrict__ out, const int B,
+                                                        const int cols, const int cols4) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * cols) return;
+    const int c = i % cols;
+    float v = ((p0[i] + p1[i]) + p2[i]) + p3[i];
+    if (c < cols4) v += p4[i];
+    out[i] = v;
+}
+
 // inverted dropout in place; keep = hash(seed, stream, idx) >= p
 __device__ __forceinline__ unsigned int mix32(unsigned long long x) {
     x += 0x9E3779B97F4A7C15ull;
@@ -387,6 +403,13 @@ int launch_colsum(const float* dy, float* db, int B, int out, int dy_ld, int acc
 int launch_relu_mask(float* d, const float* act, int B, int cols, int d_ld, int act_ld,
                      float scale, hipStream_t s) {
     relu_mask_kernel<<<cdiv(B * cols, 256), 256, 0, s>>>(d, act, B, cols, d_ld, act_ld, scale);
+    CILRS_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_sum_parts(const float* p0, const float* p1, const float* p2, const float* p3,
+                     const float* p4, float* out, int B, int cols, int cols4, hipStream_t s) {
+    sum_parts_kernel<<<cdiv(B * cols, 256), 256, 0, s>>>(p0, p1, p2, p3, p4, out, B, cols, cols4);
     CILRS_LAUNCH_CHECK();
     return 0;
 }

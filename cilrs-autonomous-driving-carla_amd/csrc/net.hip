@@ -215,12 +215,28 @@ struct cilrs_net {
     int featHW;
     // workspace offsets (in floats unless noted)
     size_t x4, w4, pool, argmax_b /*bytes offset*/, combined, s1, p1, p2, h1[4], h2[4], all_out;
-    size_t dcombined, ds1, dp1, dp2, dh1, dh2, d_all, speed_in, cmd_b /*bytes offset*/;
-    size_t G[4];                           // rotating gradient buffers (max activation size)
+    size_t dcombined, ds1, dp1, dp2, dh1[4], dh2[4], dcomb_part[5], d_all, speed_in,
+        cmd_b /*bytes offset*/;
+    size_t hscr[5], hscr_floats, hslab[5], hslab_floats;   // per-chain scratch of the heads
+    size_t G[5];                           // rotating gradient buffers (max activation size)
     size_t gmax;
     size_t bn_partial, bn_coef, slabs, slabs_floats, ksplit, ksplit_floats, status_b;
     size_t ws_bytes;
     float* ws_base = nullptr;             // workspace of the current call (set by every entry)
+    // side streams: independent kernels (weight-gradient vs data-gradient GEMMs, the five head
+    // chains) run concurrently so one launch's tail fills with another's blocks
+    bool overlap = true;
+    bool streams_ready = false;
+    hipStream_t side[5];
+    hipEvent_t fork_ev, join_ev[5], gbuf_ev[5];
+    bool gbuf_pending[5] = {false, false, false, false, false};
+    int dy_toggle = 0;
+    BnEvalTable bn_table;
+    // cached hipGraph of the uint8 inference path (fixed pointers)
+    hipGraphExec_t graph_exec = nullptr;
+    const void* graph_key[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                nullptr};
+    bool warmed = false;
     bool trained_fwd = false;
     float last_dropout = 0.f;
     Prof prof;
@@ -257,17 +273,85 @@ struct Bump {
         }                                                                             \
     } while (0)
 
+int ensure_streams(cilrs_net* net) {
+    if (net->streams_ready) return 0;
+    for (int i = 0; i < 5; ++i) {
+        CILRS_HIP(hipStreamCreateWithFlags(&net->side[i], hipStreamNonBlocking));
+        CILRS_HIP(hipEventCreateWithFlags(&net->join_ev[i], hipEventDisableTiming));
+        CILRS_HIP(hipEventCreateWithFlags(&net->gbuf_ev[i], hipEventDisableTiming));
+    }
+    CILRS_HIP(hipEventCreateWithFlags(&net->fork_ev, hipEventDisableTiming));
+    net->streams_ready = true;
+    return 0;
+}
+// concurrency is switched off while per-kernel timing is on (serial brackets are meaningful)
+bool use_overlap(cilrs_net* net) { return net->overlap && !net->prof.on; }
+// side streams [0,n) start after everything enqueued on `main` so far
+int fork_streams(cilrs_net* net, hipStream_t main, int n) {
+    if (!use_overlap(net)) return 0;
+    if (ensure_streams(net)) return 1;
+    CILRS_HIP(hipEventRecord(net->fork_ev, main));
+    for (int i = 0; i < n; ++i) CILRS_HIP(hipStreamWaitEvent(net->side[i], net->fork_ev, 0));
+    return 0;
+}
+int join_streams(cilrs_net* net, hipStream_t main, int n) {
+    if (!use_overlap(net)) return 0;
+    for (int i = 0; i < n; ++i) {
+        CILRS_HIP(hipEventRecord(net->join_ev[i], net->side[i]));
+        CILRS_HIP(hipStreamWaitEvent(main, net->join_ev[i], 0));
+    }
+    return 0;
+}
+hipStream_t side_or(cilrs_net* net, hipStream_t main, int i) {
+    return use_overlap(net) ? net->side[i] : main;
+}
+// gradient buffer `gi` is about to be overwritten on `main`: wait for a side-stream reader
+int gbuf_acquire(cilrs_net* net, hipStream_t main, int gi) {
+    if (net->gbuf_pending[gi]) {
+        CILRS_HIP(hipStreamWaitEvent(main, net->gbuf_ev[gi], 0));
+        net->gbuf_pending[gi] = false;
+    }
+    return 0;
+}
+// side stream 0 will read gradient buffer `gi` (just produced on `main`)
+int gbuf_side_begin(cilrs_net* net, hipStream_t main) {
+    if (!use_overlap(net)) return 0;
+    if (ensure_streams(net)) return 1;
+    CILRS_HIP(hipEventRecord(net->fork_ev, main));
+    CILRS_HIP(hipStreamWaitEvent(net->side[0], net->fork_ev, 0));
+    return 0;
+}
+int gbuf_side_end(cilrs_net* net, int gi) {
+    if (!use_overlap(net)) return 0;
+    CILRS_HIP(hipEventRecord(net->gbuf_ev[gi], net->side[0]));
+    net->gbuf_pending[gi] = true;
+    return 0;
+}
+int gbuf_join_all(cilrs_net* net, hipStream_t main) {
+    for (int gi = 0; gi < 5; ++gi)
+        if (gbuf_acquire(net, main, gi)) return 1;
+    return 0;
+}
+
 int conv_fwd(cilrs_net* net, const ConvT& c, const ConvG& g, const float* x, int x_cin,
-             const float* w, float* y, float* ws, hipStream_t s) {
+             const float* w, float* y, float* ws, hipStream_t s, int* bn_nblk = nullptr,
+             const float* fold_stats = nullptr, int relu = 0, const float* addend = nullptr,
+             int relu_post = 0) {
     ConvArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x; a.w = w; a.y = y;
+    if (fold_stats) {            // eval-mode BatchNorm (+ReLU / residual) folded into the epilogue
+        a.ch_scale = fold_stats + 2 * c.cout;
+        a.ch_shift = fold_stats + 3 * c.cout;
+        a.relu = relu; a.addend = addend; a.relu_post = relu_post;
+    }
     a.N = net->B; a.H = g.H; a.W = g.W; a.Cin = x_cin;
     a.Ho = g.Ho; a.Wo = g.Wo; a.Cout = c.cout;
     a.KH = a.KW = c.k; a.stride = c.stride; a.pad = c.pad;
     a.x_ld = x_cin; a.y_ld = c.cout; a.w_mode = 0; a.w_cin = x_cin;
     a.scratch = ws + net->ksplit; a.scratch_floats = net->ksplit_floats;
     a.force_cfg = -1;
+    if (bn_nblk) { a.bn_partial = ws + net->bn_partial; a.bn_nblk = bn_nblk; *bn_nblk = 0; }
     const double flops = 2.0 * g.M * c.cout * c.k * c.k * c.cin;
     const double bytes = 4.0 * ((double)net->B * g.H * g.W * c.cin + (double)g.M * c.cout +
                                 (double)c.cout * c.k * c.k * c.cin);
@@ -315,14 +399,14 @@ int conv_wgrad(cilrs_net* net, const ConvT& c, const ConvG& g, const float* x, i
 
 // wide linear layer on the matrix pipe: y[B][out] = relu?(x[B][in] W^T + b)
 int lin_fwd(cilrs_net* net, const LinT& l, const float* P, const float* x, int x_ld, float* y,
-            int y_ld, int relu, hipStream_t s) {
+            int y_ld, int relu, int chain, hipStream_t s) {
     ConvArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x; a.w = P + l.w; a.y = y; a.bias = P + l.b;
     a.N = net->B; a.H = 1; a.W = 1; a.Cin = l.in; a.Ho = 1; a.Wo = 1; a.Cout = l.out;
     a.KH = a.KW = 1; a.stride = 1; a.pad = 0;
     a.x_ld = x_ld; a.y_ld = y_ld; a.w_mode = 0; a.w_cin = l.in; a.relu = relu;
-    a.scratch = net->ws_base + net->ksplit; a.scratch_floats = net->ksplit_floats;
+    a.scratch = net->ws_base + net->hscr[chain]; a.scratch_floats = net->hscr_floats;
     a.force_cfg = -1;
     RUN(net, "heads_fwd", 2.0 * net->B * l.in * l.out, 4.0 * l.in * l.out, s,
         launch_conv_igemm(a, s));
@@ -332,7 +416,7 @@ int lin_fwd(cilrs_net* net, const LinT& l, const float* P, const float* x, int x
 // dx[B][in] = (dy[B][out] W) [masked by act>0, scaled] [+ addend]
 int lin_dgrad(cilrs_net* net, const LinT& l, const float* P, const float* dy, int dy_ld,
               float* dx, int dx_ld, const float* act, int act_ld, float act_scale,
-              const float* addend, hipStream_t s) {
+              const float* addend, int chain, hipStream_t s) {
     DgradArgs a;
     memset(&a, 0, sizeof(a));
     a.dy = dy; a.w = P + l.w; a.dx = dx; a.addend = addend;
@@ -340,7 +424,7 @@ int lin_dgrad(cilrs_net* net, const LinT& l, const float* P, const float* dy, in
     a.N = net->B; a.H = 1; a.W = 1; a.Cin = l.in; a.Ho = 1; a.Wo = 1; a.Cout = l.out;
     a.K = 1; a.stride = 1; a.pad = 0;
     a.dy_ld = dy_ld; a.dx_ld = dx_ld;
-    a.scratch = net->ws_base + net->ksplit; a.scratch_floats = net->ksplit_floats;
+    a.scratch = net->ws_base + net->hscr[chain]; a.scratch_floats = net->hscr_floats;
     a.force_cfg = -1;
     RUN(net, "heads_bwd", 2.0 * net->B * l.in * l.out, 4.0 * l.in * l.out, s,
         launch_conv_dgrad(a, s));
@@ -349,14 +433,14 @@ int lin_dgrad(cilrs_net* net, const LinT& l, const float* P, const float* dy, in
 
 // dW[out][in] = dy^T x ; db = colsum(dy)
 int lin_wgrad(cilrs_net* net, const LinT& l, float* Gp, const float* x, int x_ld, const float* dy,
-              int dy_ld, float* ws, hipStream_t s) {
+              int dy_ld, float* ws, int chain, hipStream_t s) {
     WgradArgs a;
     memset(&a, 0, sizeof(a));
-    a.x = x; a.dy = dy; a.dw = Gp + l.w; a.slabs = ws + net->slabs;
+    a.x = x; a.dy = dy; a.dw = Gp + l.w; a.slabs = ws + net->hslab[chain];
     a.N = net->B; a.H = 1; a.W = 1; a.Cin = l.in; a.Ho = 1; a.Wo = 1; a.Cout = l.out;
     a.KH = a.KW = 1; a.stride = 1; a.pad = 0;
     a.x_ld = x_ld; a.dy_ld = dy_ld; a.Cin_dst = l.in; a.accumulate = 0;
-    CILRS_CHECK(wgrad_scratch_floats(a) <= net->slabs_floats, "wgrad scratch too small (heads)");
+    CILRS_CHECK(wgrad_scratch_floats(a) <= net->hslab_floats, "wgrad scratch too small (heads)");
     RUN(net, "heads_bwd", 2.0 * net->B * l.in * l.out, 4.0 * l.in * l.out, s,
         launch_conv_wgrad(a, s));
     RUN(net, "heads_bwd", 0.0, 0.0, s, launch_colsum(dy, Gp + l.b, net->B, l.out, dy_ld, 0, s));
@@ -504,8 +588,17 @@ int cilrs_net_create(int batch, int height, int width, cilrs_net** out) {
     n->ds1 = bump.take((size_t)B * 128);
     n->dp1 = bump.take((size_t)B * 256);
     n->dp2 = bump.take((size_t)B * 256);
-    n->dh1 = bump.take((size_t)B * 256);
-    n->dh2 = bump.take((size_t)B * 256);
+    for (int k = 0; k < 4; ++k) {
+        n->dh1[k] = bump.take((size_t)B * 256);
+        n->dh2[k] = bump.take((size_t)B * 256);
+    }
+    for (int k = 0; k < 5; ++k) n->dcomb_part[k] = bump.take((size_t)B * 640);
+    n->hscr_floats = (size_t)16 * B * 640;
+    n->hslab_floats = (size_t)2 * 256 * 640;
+    for (int k = 0; k < 5; ++k) {
+        n->hscr[k] = bump.take(n->hscr_floats);
+        n->hslab[k] = bump.take(n->hslab_floats);
+    }
     n->d_all = bump.take((size_t)4 * B * 4);
     n->speed_in = bump.take((size_t)B);
     n->cmd_b = bump.take((size_t)B * 2) * sizeof(float);
@@ -519,20 +612,46 @@ int cilrs_net_create(int batch, int height, int width, cilrs_net** out) {
         if (sf > slabs_max) slabs_max = sf;
     }
     n->gmax = gmax;
-    for (int i = 0; i < 4; ++i) n->G[i] = bump.take(gmax);
-    n->bn_partial = bump.take(bn_partial_floats(512));
+    for (int i = 0; i < 5; ++i) n->G[i] = bump.take(gmax);
+    {
+        size_t need = bn_partial_floats(512);
+        for (size_t ci = 0; ci < A.convs.size(); ++ci) {
+            const size_t t = (size_t)cdiv(n->cg[ci].M, 64) * 2 * A.convs[ci].cout;
+            if (t > need) need = t;
+        }
+        n->bn_partial = bump.take(need);
+    }
     n->bn_coef = bump.take(3 * 512);
     n->slabs_floats = slabs_max;
     n->slabs = bump.take(slabs_max);
     n->ksplit_floats = ksplit_max;
     n->ksplit = bump.take(ksplit_max > 0 ? ksplit_max : 4);
     n->status_b = bump.take(64) * sizeof(float);
+    n->bn_table.n = (int)A.convs.size();
+    for (size_t ci = 0; ci < A.convs.size(); ++ci) {
+        const BnT& b = A.bns[A.convs[ci].bn];
+        n->bn_table.C[ci] = b.C;
+        n->bn_table.gamma[ci] = (unsigned)b.gamma; n->bn_table.beta[ci] = (unsigned)b.beta;
+        n->bn_table.rm[ci] = (unsigned)b.rm; n->bn_table.rv[ci] = (unsigned)b.rv;
+        n->bn_table.stats[ci] = (unsigned)n->cg[ci].stats;
+    }
     n->ws_bytes = bump.off * sizeof(float);
     *out = n;
     return 0;
 }
 
-void cilrs_net_destroy(cilrs_net* net) { delete net; }
+void cilrs_net_destroy(cilrs_net* net) {
+    if (net && net->streams_ready) {
+        for (int i = 0; i < 5; ++i) {
+            (void)hipStreamDestroy(net->side[i]);
+            (void)hipEventDestroy(net->join_ev[i]);
+            (void)hipEventDestroy(net->gbuf_ev[i]);
+        }
+        (void)hipEventDestroy(net->fork_ev);
+    }
+    if (net && net->graph_exec) (void)hipGraphExecDestroy(net->graph_exec);
+    delete net;
+}
 size_t cilrs_net_workspace_bytes(const cilrs_net* net) { return net ? net->ws_bytes : 0; }
 
 // ------------------------------------------------------------------------------------------------
@@ -549,7 +668,7 @@ static int forward_from_x4(cilrs_net* net, const cilrs_buffers* bufs, const floa
     const int B = net->B;
     const float eps = 1e-5f, mom = 0.1f;
 
-    auto bn = [&](int ci, const float* residual, int relu) -> int {
+    auto bn = [&](int ci, const float* residual, int relu, int pre_nblk) -> int {
         const ConvT& c = A.convs[ci];
         const ConvG& g = net->cg[ci];
         const BnT& b = A.bns[c.bn];
@@ -559,7 +678,7 @@ static int forward_from_x4(cilrs_net* net, const cilrs_buffers* bufs, const floa
                 launch_bn_train_fwd(ws + g.y, g.M, c.cout, P + b.gamma, P + b.beta, R + b.rm,
                                     R + b.rv, reinterpret_cast<long long*>(bufs->bn_nbt) + c.bn,
                                     mom, eps, residual, relu, ws + g.stats, ws + net->bn_partial,
-                                    ws + g.z, s));
+                                    ws + g.z, pre_nblk, s));
         } else {
             RUN(net, std::string("bn_fwd.") + kGroupName[c.group], 0.0, bytes, s,
                 launch_bn_eval_fwd(ws + g.y, g.M, c.cout, P + b.gamma, P + b.beta, R + b.rm,
@@ -571,34 +690,71 @@ static int forward_from_x4(cilrs_net* net, const cilrs_buffers* bufs, const floa
     // ---- stem: conv7x7/s2 + BN + ReLU + maxpool3x3/s2 ----
     RUN(net, "transform", 0.0, 0.0, s,
         launch_pad_cin3_to_4(P + A.convs[0].w, ws + net->w4, 64 * 49, s));
-    if (conv_fwd(net, A.convs[0], net->cg[0], ws + net->x4, 4, ws + net->w4, ws + net->cg[0].y,
-                 ws, s)) return 1;
-    if (bn(0, nullptr, 1)) return 1;
-    unsigned char* argmax = reinterpret_cast<unsigned char*>(bufs->workspace) + net->argmax_b;
-    RUN(net, "maxpool", 0.0, 4.0 * net->cg[0].M * 64 * 1.25, s,
-        launch_maxpool_fwd(ws + net->cg[0].z, ws + net->pool, train ? argmax : nullptr, B,
-                           net->H0, net->W0, 64, s));
-
-    // ---- BasicBlocks ----
-    const float* cur = ws + net->pool;
-    for (const BlockT& blk : A.blocks) {
-        const ConvT& c1 = A.convs[blk.conv1];
-        const ConvT& c2 = A.convs[blk.conv2];
-        const ConvG& g1 = net->cg[blk.conv1];
-        const ConvG& g2 = net->cg[blk.conv2];
-        if (conv_fwd(net, c1, g1, cur, c1.cin, P + c1.w, ws + g1.y, ws, s)) return 1;
-        if (bn(blk.conv1, nullptr, 1)) return 1;
-        if (conv_fwd(net, c2, g2, ws + g1.z, c2.cin, P + c2.w, ws + g2.y, ws, s)) return 1;
-        const float* identity = cur;
-        if (blk.down >= 0) {
-            const ConvT& cd = A.convs[blk.down];
-            const ConvG& gd = net->cg[blk.down];
-            if (conv_fwd(net, cd, gd, cur, cd.cin, P + cd.w, ws + gd.y, ws, s)) return 1;
-            if (bn(blk.down, nullptr, 0)) return 1;
-            identity = ws + gd.z;
+    const float* cur;
+    if (train) {
+        int nb = 0;                             // batch statistics fused into the conv epilogue
+        if (conv_fwd(net, A.convs[0], net->cg[0], ws + net->x4, 4, ws + net->w4,
+                     ws + net->cg[0].y, ws, s, &nb)) return 1;
+        if (bn(0, nullptr, 1, nb)) return 1;
+        unsigned char* argmax = reinterpret_cast<unsigned char*>(bufs->workspace) + net->argmax_b;
+        RUN(net, "maxpool", 0.0, 4.0 * net->cg[0].M * 64 * 1.25, s,
+            launch_maxpool_fwd(ws + net->cg[0].z, ws + net->pool, argmax, B, net->H0, net->W0,
+                               64, s));
+        // ---- BasicBlocks ----
+        cur = ws + net->pool;
+        for (const BlockT& blk : A.blocks) {
+            const ConvT& c1 = A.convs[blk.conv1];
+            const ConvT& c2 = A.convs[blk.conv2];
+            const ConvG& g1 = net->cg[blk.conv1];
+            const ConvG& g2 = net->cg[blk.conv2];
+            nb = 0;
+            if (conv_fwd(net, c1, g1, cur, c1.cin, P + c1.w, ws + g1.y, ws, s, &nb)) return 1;
+            if (bn(blk.conv1, nullptr, 1, nb)) return 1;
+            const float* identity = cur;
+            if (blk.down >= 0) {
+                const ConvT& cd = A.convs[blk.down];
+                const ConvG& gd = net->cg[blk.down];
+                nb = 0;
+                if (conv_fwd(net, cd, gd, cur, cd.cin, P + cd.w, ws + gd.y, ws, s, &nb)) return 1;
+                if (bn(blk.down, nullptr, 0, nb)) return 1;
+                identity = ws + gd.z;
+            }
+            nb = 0;
+            if (conv_fwd(net, c2, g2, ws + g1.z, c2.cin, P + c2.w, ws + g2.y, ws, s, &nb))
+                return 1;
+            if (bn(blk.conv2, identity, 1, nb)) return 1;
+            cur = ws + g2.z;
         }
-        if (bn(blk.conv2, identity, 1)) return 1;
-        cur = ws + g2.z;
+    } else {
+        // eval: running statistics -> per-channel scale/shift (one launch for all 36 layers),
+        // folded with ReLU / residual add into each conv's epilogue; no pre-BN tensor is stored
+        RUN(net, "bn_fwd.eval", 0.0, 0.0, s,
+            launch_bn_eval_stats_all(net->bn_table, P, R, ws, eps, s));
+        if (conv_fwd(net, A.convs[0], net->cg[0], ws + net->x4, 4, ws + net->w4,
+                     ws + net->cg[0].z, ws, s, nullptr, ws + net->cg[0].stats, 1)) return 1;
+        RUN(net, "maxpool", 0.0, 4.0 * net->cg[0].M * 64 * 1.25, s,
+            launch_maxpool_fwd(ws + net->cg[0].z, ws + net->pool, nullptr, B, net->H0, net->W0,
+                               64, s));
+        cur = ws + net->pool;
+        for (const BlockT& blk : A.blocks) {
+            const ConvT& c1 = A.convs[blk.conv1];
+            const ConvT& c2 = A.convs[blk.conv2];
+            const ConvG& g1 = net->cg[blk.conv1];
+            const ConvG& g2 = net->cg[blk.conv2];
+            if (conv_fwd(net, c1, g1, cur, c1.cin, P + c1.w, ws + g1.z, ws, s, nullptr,
+                         ws + g1.stats, 1)) return 1;
+            const float* identity = cur;
+            if (blk.down >= 0) {
+                const ConvT& cd = A.convs[blk.down];
+                const ConvG& gd = net->cg[blk.down];
+                if (conv_fwd(net, cd, gd, cur, cd.cin, P + cd.w, ws + gd.z, ws, s, nullptr,
+                             ws + gd.stats, 0)) return 1;
+                identity = ws + gd.z;
+            }
+            if (conv_fwd(net, c2, g2, ws + g1.z, c2.cin, P + c2.w, ws + g2.z, ws, s, nullptr,
+                         ws + g2.stats, 0, identity, 1)) return 1;
+            cur = ws + g2.z;
+        }
     }
 
     // ---- avgpool + flatten -> combined[:, 0:512] ----
@@ -612,38 +768,46 @@ static int forward_from_x4(cilrs_net* net, const cilrs_buffers* bufs, const floa
                                  (size_t)B * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
     }
     const float pdrop = train ? dropout_p : 0.f;
-    auto drop = [&](float* a, int cols, int ld, unsigned long long stream_id) -> int {
+    auto drop = [&](float* a, int cols, int ld, unsigned long long stream_id,
+                    hipStream_t q) -> int {
         if (pdrop > 0.f)
-            RUN(net, "heads_fwd", 0.0, 0.0, s, launch_dropout(a, B, cols, ld, pdrop, seed,
-                                                              stream_id, s));
+            RUN(net, "heads_fwd", 0.0, 0.0, q, launch_dropout(a, B, cols, ld, pdrop, seed,
+                                                              stream_id, q));
         return 0;
     };
     // ---- speed encoder (autonomous_drive.py:371-374, 391) ----
     RUN(net, "heads_fwd", 0.0, 0.0, s,
         launch_linear_small_fwd(speed, P + A.se0.w, P + A.se0.b, ws + net->s1, B, 1, 128, 1, 128,
                                 1, s));
-    if (drop(ws + net->s1, 128, 128, 0)) return 1;
-    if (lin_fwd(net, A.se3, P, ws + net->s1, 128, ws + net->combined + 512, 640, 1, s)) return 1;
-    // ---- speed predictor (:383-387, 393) on the visual features ----
-    if (lin_fwd(net, A.sp0, P, ws + net->combined, 640, ws + net->p1, 256, 1, s)) return 1;
-    if (drop(ws + net->p1, 256, 256, 9)) return 1;
-    if (lin_fwd(net, A.sp3, P, ws + net->p1, 256, ws + net->p2, 256, 1, s)) return 1;
-    RUN(net, "heads_fwd", 0.0, 0.0, s,
-        launch_linear_small_fwd(ws + net->p2, P + A.sp5.w, P + A.sp5.b, pred_speed, B, 256, 1,
-                                256, 1, 0, s));
-    // ---- four branches, all evaluated (:394-396), then gathered by command (:397-398) ----
+    if (drop(ws + net->s1, 128, 128, 0, s)) return 1;
+    if (lin_fwd(net, A.se3, P, ws + net->s1, 128, ws + net->combined + 512, 640, 1, 4, s)) return 1;
+    // ---- five independent chains on side streams: 4 branches (all evaluated, :394-396) and
+    //      the speed predictor (:383-387, 393) ----
+    if (fork_streams(net, s, 5)) return 1;
+    {
+        hipStream_t q = side_or(net, s, 4);
+        if (lin_fwd(net, A.sp0, P, ws + net->combined, 640, ws + net->p1, 256, 1, 4, q)) return 1;
+        if (drop(ws + net->p1, 256, 256, 9, q)) return 1;
+        if (lin_fwd(net, A.sp3, P, ws + net->p1, 256, ws + net->p2, 256, 1, 4, q)) return 1;
+        RUN(net, "heads_fwd", 0.0, 0.0, q,
+            launch_linear_small_fwd(ws + net->p2, P + A.sp5.w, P + A.sp5.b, pred_speed, B, 256, 1,
+                                    256, 1, 0, q));
+    }
     for (int k = 0; k < 4; ++k) {
-        if (lin_fwd(net, A.br[k][0], P, ws + net->combined, 640, ws + net->h1[k], 256, 1, s))
+        hipStream_t q = side_or(net, s, k);
+        if (lin_fwd(net, A.br[k][0], P, ws + net->combined, 640, ws + net->h1[k], 256, 1, k, q))
             return 1;
-        if (drop(ws + net->h1[k], 256, 256, 1 + 2 * k)) return 1;
-        if (lin_fwd(net, A.br[k][1], P, ws + net->h1[k], 256, ws + net->h2[k], 256, 1, s))
+        if (drop(ws + net->h1[k], 256, 256, 1 + 2 * k, q)) return 1;
+        if (lin_fwd(net, A.br[k][1], P, ws + net->h1[k], 256, ws + net->h2[k], 256, 1, k, q))
             return 1;
-        if (drop(ws + net->h2[k], 256, 256, 2 + 2 * k)) return 1;
-        RUN(net, "heads_fwd", 0.0, 0.0, s,
+        if (drop(ws + net->h2[k], 256, 256, 2 + 2 * k, q)) return 1;
+        RUN(net, "heads_fwd", 0.0, 0.0, q,
             launch_linear_small_fwd(ws + net->h2[k], P + A.br[k][2].w, P + A.br[k][2].b,
                                     ws + net->all_out + (size_t)k * B * 4, B, 256, 3, 256, 4, 0,
-                                    s));
+                                    q));
     }
+    if (join_streams(net, s, 5)) return 1;
+    // gathered by command (:397-398)
     int* status = reinterpret_cast<int*>(reinterpret_cast<char*>(bufs->workspace) + net->status_b);
     RUN(net, "heads_fwd", 0.0, 0.0, s,
         launch_branch_gather(ws + net->all_out, reinterpret_cast<const long long*>(command),
@@ -691,6 +855,48 @@ int cilrs_net_forward_u8(cilrs_net* net, const cilrs_buffers* bufs, const uint8_
         launch_u8hwc_to_nhwc4(frames, ws + net->x4, (size_t)net->B * net->H * net->W, mean, stdv,
                               s));
     return forward_from_x4(net, bufs, speed, command, 0, 0.f, 0, controls, pred_speed, s);
+}
+
+// Same as cilrs_net_forward_u8, replayed from a cached hipGraph (one launch per frame instead of
+// ~80): the B=1 control-loop path (autonomous_drive.py:908-920) is launch-latency bound.  The
+// graph is re-captured when any pointer changes.  `stream` must not be the legacy NULL stream.
+int cilrs_net_forward_u8_graph(cilrs_net* net, const cilrs_buffers* bufs, const uint8_t* frames,
+                               const float* speed, const int64_t* command, float* controls,
+                               float* pred_speed, void* stream) {
+    if (check_bufs(net, bufs, false)) return 1;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    CILRS_CHECK(s != nullptr, "forward_u8_graph: capture needs a non-default stream");
+    const void* key[8] = {bufs->params, bufs->bn_running, bufs->workspace, frames, speed, command,
+                          controls, pred_speed};
+    bool same = net->graph_exec != nullptr;
+    for (int i = 0; i < 8 && same; ++i) same = key[i] == net->graph_key[i];
+    if (!same) {
+        if (!net->warmed) {      // first call eager: function attributes, side streams, events
+            if (ensure_streams(net)) return 1;
+            if (cilrs_net_forward_u8(net, bufs, frames, speed, command, controls, pred_speed,
+                                     stream)) return 1;
+            CILRS_HIP(hipStreamSynchronize(s));
+            net->warmed = true;
+        }
+        const bool prof = net->prof.on;
+        net->prof.on = false;
+        hipGraph_t graph = nullptr;
+        CILRS_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        const int rc = cilrs_net_forward_u8(net, bufs, frames, speed, command, controls,
+                                            pred_speed, stream);
+        const hipError_t e = hipStreamEndCapture(s, &graph);
+        net->prof.on = prof;
+        CILRS_CHECK(rc == 0, "forward_u8_graph: capture failed: %s", last_error());
+        CILRS_CHECK(e == hipSuccess && graph != nullptr, "hipStreamEndCapture failed: %s",
+                    hipGetErrorString(e));
+        if (net->graph_exec) { (void)hipGraphExecDestroy(net->graph_exec); net->graph_exec = nullptr; }
+        const hipError_t e2 = hipGraphInstantiate(&net->graph_exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        CILRS_CHECK(e2 == hipSuccess, "hipGraphInstantiate failed: %s", hipGetErrorString(e2));
+        for (int i = 0; i < 8; ++i) net->graph_key[i] = key[i];
+    }
+    CILRS_HIP(hipGraphLaunch(net->graph_exec, s));
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -741,25 +947,41 @@ int cilrs_net_backward(cilrs_net* net, const cilrs_buffers* bufs, const float* d
                 if (bi == 0) xin = ws + net->pool;
                 else xin = ws + net->cg[A.blocks[bi - 1].conv2].z;
                 float* Gd = ws + net->G[3];
-                float* Ga = ws + net->G[0];
                 float* Gb = ws + net->G[1];
                 float* Gc = ws + net->G[2];
                 const std::string grp = kGroupName[c1.group];
+                // weight gradients run on side stream 0, concurrently with the data gradients
+                auto wgrad_side = [&](const ConvT& c, const ConvG& g, const float* x, int gi,
+                                      float* dwdst) -> int {
+                    if (gbuf_side_begin(net, s)) return 1;
+                    if (conv_wgrad(net, c, g, x, c.cin, ws + net->G[gi], dwdst, ws,
+                                   side_or(net, s, 0))) return 1;
+                    return gbuf_side_end(net, gi);
+                };
                 // 1. out = relu(bn2(y2) + identity): masked grad -> Gb, dy2 -> Ga
+                int ga = net->dy_toggle ? 4 : 0;
+                net->dy_toggle ^= 1;
+                if (gbuf_acquire(net, s, ga) || gbuf_acquire(net, s, 1)) return 1;
+                float* Ga = ws + net->G[ga];
                 RUN(net, "bn_bwd." + grp, 0.0, 4.0 * g2.M * c2.cout * 8.0, s,
                     launch_bn_bwd(Gd, ws + g2.z, ws + g2.y, g2.M, c2.cout, P + b2.gamma,
                                   ws + g2.stats, 1, Gp + b2.gamma, Gp + b2.beta, 0,
                                   ws + net->bn_coef, ws + net->bn_partial, Ga, Gb, s));
-                // 2./3. conv2: dW2, da -> Gc
-                if (conv_wgrad(net, c2, g2, ws + g1.z, c2.cin, Ga, Gp + c2.w, ws, s)) return 1;
+                // 2./3. conv2: dW2 (side), da -> Gc
+                if (wgrad_side(c2, g2, ws + g1.z, ga, Gp + c2.w)) return 1;
+                if (gbuf_acquire(net, s, 2)) return 1;
                 if (conv_dgrad(net, c2, g2, Ga, P + c2.w, Gc, nullptr, ws, s)) return 1;
-                // 4. a = relu(bn1(y1)): dy1 -> Ga
+                // 4. a = relu(bn1(y1)): dy1 -> the other dy buffer
+                ga = net->dy_toggle ? 4 : 0;
+                net->dy_toggle ^= 1;
+                if (gbuf_acquire(net, s, ga)) return 1;
+                Ga = ws + net->G[ga];
                 RUN(net, "bn_bwd." + grp, 0.0, 4.0 * g1.M * c1.cout * 7.0, s,
                     launch_bn_bwd(Gc, ws + g1.z, ws + g1.y, g1.M, c1.cout, P + b1.gamma,
                                   ws + g1.stats, 1, Gp + b1.gamma, Gp + b1.beta, 0,
                                   ws + net->bn_coef, ws + net->bn_partial, Ga, nullptr, s));
-                // 5. dW1
-                if (conv_wgrad(net, c1, g1, xin, c1.cin, Ga, Gp + c1.w, ws, s)) return 1;
+                // 5. dW1 (side)
+                if (wgrad_side(c1, g1, xin, ga, Gp + c1.w)) return 1;
                 if (blk.down < 0) {
                     // 6. dx = dgrad(conv1) + identity grad (Gb) -> Gd
                     if (conv_dgrad(net, c1, g1, Ga, P + c1.w, Gd, Gb, ws, s)) return 1;
@@ -769,15 +991,18 @@ int cilrs_net_backward(cilrs_net* net, const cilrs_buffers* bufs, const float* d
                     const BnT& bd = A.bns[cd.bn];
                     if (conv_dgrad(net, c1, g1, Ga, P + c1.w, Gd, nullptr, ws, s)) return 1;
                     // 7. identity = bn_d(conv_d(x)) (no ReLU): dy_d -> Gc
+                    if (gbuf_acquire(net, s, 2)) return 1;
                     RUN(net, "bn_bwd." + grp, 0.0, 4.0 * gd.M * cd.cout * 6.0, s,
                         launch_bn_bwd(Gb, nullptr, ws + gd.y, gd.M, cd.cout, P + bd.gamma,
                                       ws + gd.stats, 0, Gp + bd.gamma, Gp + bd.beta, 0,
                                       ws + net->bn_coef, ws + net->bn_partial, Gc, nullptr, s));
-                    if (conv_wgrad(net, cd, gd, xin, cd.cin, Gc, Gp + cd.w, ws, s)) return 1;
+                    if (wgrad_side(cd, gd, xin, 2, Gp + cd.w)) return 1;
                     // 8. dx += dgrad(conv_d)
                     if (conv_dgrad(net, cd, gd, Gc, P + cd.w, Gd, Gd, ws, s)) return 1;
                 }
             }
+            // the segment's weight gradients are complete when this call returns its work
+            if (gbuf_join_all(net, s)) return 1;
             continue;
         }
         // seg == 5: stem.  G[3] holds d(maxpool output)
@@ -815,38 +1040,50 @@ static int backward_heads(cilrs_net* net, const cilrs_buffers* bufs, const float
 
     // ---- branches: only the commanded branch of each frame receives gradient (gather) ----
     RUN(net, "heads_bwd", 0.0, 0.0, s, launch_branch_scatter(dcontrols, cmd, ws + net->d_all, B, 4, s));
+    if (fork_streams(net, s, 5)) return 1;
     for (int k = 0; k < 4; ++k) {
+        hipStream_t q = side_or(net, s, k);
         const float* d_ok = ws + net->d_all + (size_t)k * B * 4;
+        float* dh1 = ws + net->dh1[k];
+        float* dh2 = ws + net->dh2[k];
         const LinT& l2 = A.br[k][2];
-        RUN(net, "heads_bwd", 0.0, 0.0, s,
+        RUN(net, "heads_bwd", 0.0, 0.0, q,
             launch_linear_small_bwd(d_ok, ws + net->h2[k], P + l2.w, ws + net->h2[k], dscale,
-                                    ws + net->dh2, Gp + l2.w, Gp + l2.b, B, 256, 3, 4, 256, 256,
-                                    256, 0, s));
-        if (lin_wgrad(net, A.br[k][1], Gp, ws + net->h1[k], 256, ws + net->dh2, 256, ws, s))
-            return 1;
-        if (lin_dgrad(net, A.br[k][1], P, ws + net->dh2, 256, ws + net->dh1, 256, ws + net->h1[k],
-                      256, dscale, nullptr, s)) return 1;
-        if (lin_wgrad(net, A.br[k][0], Gp, ws + net->combined, 640, ws + net->dh1, 256, ws, s))
-            return 1;
-        if (lin_dgrad(net, A.br[k][0], P, ws + net->dh1, 256, dcomb, 640, nullptr, 0, 1.f,
-                      k > 0 ? dcomb : nullptr, s)) return 1;
+                                    dh2, Gp + l2.w, Gp + l2.b, B, 256, 3, 4, 256, 256, 256, 0, q));
+        if (lin_wgrad(net, A.br[k][1], Gp, ws + net->h1[k], 256, dh2, 256, ws, k, q)) return 1;
+        if (lin_dgrad(net, A.br[k][1], P, dh2, 256, dh1, 256, ws + net->h1[k], 256, dscale,
+                      nullptr, k, q)) return 1;
+        if (lin_wgrad(net, A.br[k][0], Gp, ws + net->combined, 640, dh1, 256, ws, k, q)) return 1;
+        if (lin_dgrad(net, A.br[k][0], P, dh1, 256, ws + net->dcomb_part[k], 640, nullptr, 0, 1.f,
+                      nullptr, k, q)) return 1;
     }
     // ---- speed predictor (reads the visual half of `combined`) ----
+    {
+        hipStream_t q = side_or(net, s, 4);
+        RUN(net, "heads_bwd", 0.0, 0.0, q,
+            launch_linear_small_bwd(dps, ws + net->p2, P + A.sp5.w, ws + net->p2, 1.0f,
+                                    ws + net->dp2, Gp + A.sp5.w, Gp + A.sp5.b, B, 256, 1, 1, 256,
+                                    256, 256, 0, q));
+        if (lin_wgrad(net, A.sp3, Gp, ws + net->p1, 256, ws + net->dp2, 256, ws, 4, q)) return 1;
+        if (lin_dgrad(net, A.sp3, P, ws + net->dp2, 256, ws + net->dp1, 256, ws + net->p1, 256,
+                      dscale, nullptr, 4, q)) return 1;
+        if (lin_wgrad(net, A.sp0, Gp, ws + net->combined, 640, ws + net->dp1, 256, ws, 4, q))
+            return 1;
+        if (lin_dgrad(net, A.sp0, P, ws + net->dp1, 256, ws + net->dcomb_part[4], 640, nullptr, 0,
+                      1.f, nullptr, 4, q)) return 1;
+    }
+    if (join_streams(net, s, 5)) return 1;
+    // d combined = sum of the four branch contributions (640 wide) + speed predictor (512 wide)
     RUN(net, "heads_bwd", 0.0, 0.0, s,
-        launch_linear_small_bwd(dps, ws + net->p2, P + A.sp5.w, ws + net->p2, 1.0f, ws + net->dp2,
-                                Gp + A.sp5.w, Gp + A.sp5.b, B, 256, 1, 1, 256, 256, 256, 0, s));
-    if (lin_wgrad(net, A.sp3, Gp, ws + net->p1, 256, ws + net->dp2, 256, ws, s)) return 1;
-    if (lin_dgrad(net, A.sp3, P, ws + net->dp2, 256, ws + net->dp1, 256, ws + net->p1, 256,
-                  dscale, nullptr, s)) return 1;
-    if (lin_wgrad(net, A.sp0, Gp, ws + net->combined, 640, ws + net->dp1, 256, ws, s)) return 1;
-    if (lin_dgrad(net, A.sp0, P, ws + net->dp1, 256, dcomb, 640, nullptr, 0, 1.f, dcomb, s))
-        return 1;
+        launch_sum_parts(ws + net->dcomb_part[0], ws + net->dcomb_part[1],
+                         ws + net->dcomb_part[2], ws + net->dcomb_part[3],
+                         ws + net->dcomb_part[4], dcomb, B, 640, 512, s));
     // ---- speed encoder (the speed half of `combined`) ----
     RUN(net, "heads_bwd", 0.0, 0.0, s,
         launch_relu_mask(dcomb + 512, ws + net->combined + 512, B, 128, 640, 640, 1.0f, s));
-    if (lin_wgrad(net, A.se3, Gp, ws + net->s1, 128, dcomb + 512, 640, ws, s)) return 1;
+    if (lin_wgrad(net, A.se3, Gp, ws + net->s1, 128, dcomb + 512, 640, ws, 4, s)) return 1;
     if (lin_dgrad(net, A.se3, P, dcomb + 512, 640, ws + net->ds1, 128, ws + net->s1, 128, dscale,
-                  nullptr, s)) return 1;
+                  nullptr, 4, s)) return 1;
     RUN(net, "heads_bwd", 0.0, 0.0, s,
         launch_linear_small_bwd(ws + net->ds1, ws + net->speed_in, P + A.se0.w, nullptr, 1.0f,
                                 nullptr, Gp + A.se0.w, Gp + A.se0.b, B, 1, 128, 128, 1, 1, 1, 0,
@@ -992,7 +1229,7 @@ int cilrs_bn_train_fwd(const float* y, int M, int C, const float* gamma, const f
                        float* z, void* stream) {
     return launch_bn_train_fwd(y, M, C, gamma, beta, running_mean, running_var,
                                reinterpret_cast<long long*>(nbt), momentum, eps, residual, relu,
-                               stats, partial, z, reinterpret_cast<hipStream_t>(stream));
+                               stats, partial, z, 0, reinterpret_cast<hipStream_t>(stream));
 }
 int cilrs_bn_eval_fwd(const float* y, int M, int C, const float* gamma, const float* beta,
                       const float* running_mean, const float* running_var, float eps,

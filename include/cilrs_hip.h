@@ -79,6 +79,13 @@ int cilrs_net_forward_u8(cilrs_net* net, const cilrs_buffers* bufs, const uint8_
                          const float* speed, const int64_t* command, float* controls,
                          float* pred_speed, void* stream);
 
+/* cilrs_net_forward_u8 replayed from a cached hipGraph (re-captured when a pointer changes);
+ * `stream` must be a non-default stream.  Single-frame control loop: predict_controls,
+ * autonomous_drive.py:908-920. */
+int cilrs_net_forward_u8_graph(cilrs_net* net, const cilrs_buffers* bufs, const uint8_t* frames,
+                               const float* speed, const int64_t* command, float* controls,
+                               float* pred_speed, void* stream);
+
 /* CILRSLoss.forward + its gradient (notebook/notebook.ipynb:514-527).
  * kind 1: w0*L1(steer)+w1*L1(throttle)+w2*L1(brake)+w3*MSE(speed)     (executed config B)
  * kind 0: MSE(controls[B,3]) + w3*MSE(speed)                            (documented config A)

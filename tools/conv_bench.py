@@ -38,6 +38,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--wgrad-only", action="store_true")
     args = ap.parse_args()
     lib = L.lib()
     N = args.batch
@@ -55,7 +56,8 @@ def main():
                           device="cuda")
         flops = 2.0 * N * Ho * Wo * Cout * k * k * Cin
         res = []
-        for cfg, sk in [(-1, 0), (0, 1), (1, 1), (2, 1), (0, 2), (1, 2), (2, 2), (0, 3), (1, 3), (2, 3)]:
+        fwd_cfgs = [] if args.wgrad_only else [(-1, 0), (0, 1), (1, 1), (2, 1), (0, 2), (1, 2), (2, 2), (0, 3), (1, 3), (2, 3)]
+        for cfg, sk in fwd_cfgs:
             if cfg == 0 and Cout % 128:
                 continue
 
@@ -64,7 +66,7 @@ def main():
                                              k, s, p, cfg, sk, L.ptr(scratch), scratch.numel(), st))
             us = timeit(f, args.iters)
             res.append(f"fwd[c{cfg},k{sk}] {us:7.1f}us {flops / us / 1e6:6.1f}TF")
-        for cfg, sk in [(-1, 0), (0, 1), (1, 1), (2, 1), (1, 2), (2, 2)]:
+        for cfg, sk in ([] if args.wgrad_only else [(-1, 0), (0, 1), (1, 1), (2, 1), (1, 2), (2, 2)]):
             if cfg == 0 and Cin % 128:
                 continue
 

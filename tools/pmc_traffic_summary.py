@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Fold the rocprofv3 FETCH_SIZE / WRITE_SIZE passes of tools/pmc_traffic.sh into traffic.json.
+FETCH_SIZE is doubled (gfx950 reports half the bytes of wide coalesced reads -- MI355X_MICROARCH.md
+'HBM'); both counters are in KiB."""
+import csv
+import glob
+import json
+import sys
+
+out = sys.argv[1]
+
+
+def load(sub, counter):
+    f = glob.glob(f"{out}/{sub}/*/*_counter_collection.csv")[0]
+    agg = {}
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != counter:
+            continue
+        n = r["Kernel_Name"]
+        fam = "igemm" if "conv_igemm_kernel" in n else "wgrad" if "conv_wgrad_kernel" in n else None
+        if fam is None:
+            continue
+        a = agg.setdefault(fam, [0, 0.0])
+        a[0] += 1
+        a[1] += float(r["Counter_Value"])
+    return agg
+
+
+fe, wr = load("fetch", "FETCH_SIZE"), load("write", "WRITE_SIZE")
+res = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on `bench.py --steps 3 --warmup 1` "
+                 "(tools/pmc_traffic.sh); FETCH_SIZE x2 per the gfx950 correction; KiB -> bytes"}
+for fam in fe:
+    n = fe[fam][0]
+    rd = 2.0 * fe[fam][1] * 1024.0 / n
+    wb = wr[fam][1] * 1024.0 / max(wr[fam][0], 1)
+    res[fam] = {"launches": n, "read_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wb),
+                "bytes_per_launch": round(rd + wb)}
+json.dump(res, open(f"{out}/traffic.json", "w"), indent=1)
+print(json.dumps(res, indent=1))
