@@ -441,12 +441,12 @@ const int kBN[3] = {128, 64, 64};
 const int kOcc[3] = {2, 2, 4};
 
 Choice choose(int M, int Cout, int KT, bool allow_split, int force_cfg, int force_splitk) {
-    static const int splits[8] = {1, 2, 3, 4, 6, 8, 12, 16};
+    static const int splits[11] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48};
     Choice best{2, 1};
     double bc = 1e30;
     for (int c = 0; c < 3; ++c) {
         if (force_cfg >= 0 && c != force_cfg) continue;
-        for (int si = 0; si < 8; ++si) {
+        for (int si = 0; si < 11; ++si) {
             int sk = splits[si];
             if (force_splitk > 0) {
                 if (si > 0) break;
