@@ -94,6 +94,8 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-infer", action="store_true")
+    ap.add_argument("--force-dp", action="store_true",
+                    help="use the bucketed all-reduce path even with one rank (rehearsal)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -104,7 +106,9 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     pg = None
-    if world > 1:
+    if world > 1 or args.force_dp:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world)
         pg = dist.group.WORLD
     assert world == args.gpus or world == 1 and args.gpus == 1, \
@@ -116,7 +120,7 @@ def main():
     cfg = CONFIG_A if args.config == "A" else TrainConfig(**{**CONFIG_B.__dict__})
     model = CILRS(4, dropout=cfg.dropout).to(dev)
     trainer = Trainer(model, cfg, process_group=pg)
-    if world > 1:
+    if pg is not None:
         broadcast_parameters(trainer.eng, pg)
     batch, u8 = synthetic_batch(args.batch, 1 + rank, dev)
 
@@ -146,7 +150,7 @@ def main():
     loss_total = trainer.losses()["total"]
 
     if rank != 0:
-        if world > 1:
+        if dist.is_initialized():
             dist.destroy_process_group()
         return
     frames = args.batch * world * args.steps
@@ -257,7 +261,7 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.batch)
     print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

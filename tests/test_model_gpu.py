@@ -308,3 +308,43 @@ def test_dropout_training_runs_and_is_deterministic():
         outs.append((tr.losses()["total"], m.state_dict()["control_branches.0.3.weight"].clone()))
     assert np.isfinite(outs[0][0])
     assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_fit_loop_services(tmp_path):
+    """Epoch loop (notebook.ipynb:597-667): history CSV columns, best/latest checkpoints, StepLR,
+    validate() aggregation == the oracle's restatement of nb:563-585 on the same weights."""
+    from cilrs_mi355 import CONFIG_A, Trainer
+    from cilrs_mi355.loop import HISTORY_COLUMNS, fit
+    m = make_model()
+    tr = Trainer(m, CONFIG_A)
+    val = [O.synthetic_batch(4, seed=20 + i)[:4] for i in range(2)]
+    # validate() vs oracle before any training
+    got, cmd = tr.validate([to_dev(*b) for b in val])
+    want, wcmd = O.validate_batches(O.build_oracle(0), O.CONFIG_A, val)
+    for k in want:
+        assert abs(got[k] - want[k]) <= 1e-4 * max(1.0, abs(want[k]))
+    for k in wcmd:
+        if wcmd[k] == wcmd[k]:
+            assert abs(cmd[k] - wcmd[k]) <= 1e-4
+    train = [to_dev(*O.synthetic_batch(4, seed=70 + i)[:4]) for i in range(2)]
+    res = fit(tr, lambda: train, lambda: [to_dev(*b) for b in val], epochs=2, patience=6,
+              out_dir=str(tmp_path), log=lambda *_: None)
+    assert len(res["history"]) == 2 and res["best_epoch"] in (1, 2)
+    rows = open(tmp_path / "training_history.csv").read().strip().split("\n")
+    assert rows[0].split(",") == HISTORY_COLUMNS and len(rows) == 3
+    assert (tmp_path / "checkpoint_best.pth").exists() and (tmp_path / "checkpoint_latest.pth").exists()
+    ck = torch.load(tmp_path / "checkpoint_latest.pth", map_location="cpu", weights_only=True)
+    assert ck["epoch"] == 2 and "scheduler_state_dict" in ck
+    assert tr.epoch == 2 and tr.lr == CONFIG_A.lr            # StepLR(8, 0.5): unchanged before 8
+
+
+def test_batched_eval_matches_oracle():
+    """BASELINE config 5's shape (64-frame batches), fp32: eval forward at B=64 vs the oracle."""
+    m = make_model().eval()
+    orc = O.build_oracle(0).eval()
+    img, spd, cmd, _, _ = O.synthetic_batch(64, seed=91)
+    with torch.no_grad():
+        oc, os_ = orc(img, spd, cmd)
+        c, s = m(*to_dev(img, spd, cmd))
+    assert (c.cpu() - oc).abs().max() <= TOL_OUT
+    assert (s.cpu() - os_).abs().max() <= TOL_OUT
