@@ -102,11 +102,24 @@ __device__ __forceinline__ bool partial_sums(const float* __restrict__ partial, 
     const int ng = blockDim.x >> 5;           // 8 or 32 partial-groups
     c = blockIdx.x * 32 + cl;
     double a1 = 0.0, a2 = 0.0;
-    if (c < C)
-        for (int b = g; b < nblk; b += ng) {
-            a1 += (double)partial[(size_t)b * 2 * C + c];
-            a2 += (double)partial[(size_t)b * 2 * C + C + c];
+    if (c < C) {
+        // four independent load streams per thread (fixed order => deterministic)
+        double p1[4] = {0.0, 0.0, 0.0, 0.0}, p2[4] = {0.0, 0.0, 0.0, 0.0};
+        int b = g;
+        for (; b + 3 * ng < nblk; b += 4 * ng) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                p1[u] += (double)partial[(size_t)(b + u * ng) * 2 * C + c];
+                p2[u] += (double)partial[(size_t)(b + u * ng) * 2 * C + C + c];
+            }
         }
+        for (; b < nblk; b += ng) {
+            p1[0] += (double)partial[(size_t)b * 2 * C + c];
+            p2[0] += (double)partial[(size_t)b * 2 * C + C + c];
+        }
+        a1 = (p1[0] + p1[1]) + (p1[2] + p1[3]);
+        a2 = (p2[0] + p2[1]) + (p2[2] + p2[3]);
+    }
     red[0][g][cl] = a1;
     red[1][g][cl] = a2;
     __syncthreads();
@@ -205,7 +218,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 }
 
 // coef layout: [0,C) c1 = gamma*rstd | [C,2C) c2 = sum(g)/M | [2C,3C) c3 = sum(g*xhat)/M
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(
     const float* __restrict__ partial, const int nblk, const int M, const int C,
     const float* __restrict__ gamma, const float* __restrict__ stats, float* dgamma,
     float* dbeta, float* __restrict__ coef, const int accumulate) {
@@ -380,7 +393,7 @@ ColPlan col_plan(int M, int C) {
     const int rpi = 256 / (C >> 2);
     // >= 8 iterations of the 4-way unrolled loop per block when M allows, <= kMaxPartBlocks blocks
     int rows = cdiv(M, kMaxPartBlocks);
-    const int min_rows = 16 * rpi;
+    const int min_rows = 4 * rpi;          // at least one 4-way unrolled iteration per block
     if (rows < min_rows) rows = min_rows;
     rows = cdiv(rows, rpi) * rpi;
     ColPlan p{cdiv(M, rows), rows};
@@ -451,7 +464,7 @@ int launch_bn_bwd(const float* dz, const float* z, const float* y, int M, int C,
     bn_colreduce_kernel<1><<<p.nblk, 256, 0, s>>>(y, dz, z, stats, partial, M, C, relu,
                                                   p.rows_per_block);
     CILRS_LAUNCH_CHECK();
-    bn_bwd_finalize_kernel<<<cdiv(C, 32), 256, 0, s>>>(partial, p.nblk, M, C, gamma, stats,
+    bn_bwd_finalize_kernel<<<cdiv(C, 32), 1024, 0, s>>>(partial, p.nblk, M, C, gamma, stats,
                                                         dgamma, dbeta, coef, accumulate);
     CILRS_LAUNCH_CHECK();
     const size_t total4 = (size_t)M * C / 4;

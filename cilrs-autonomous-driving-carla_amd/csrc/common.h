@@ -85,7 +85,8 @@ struct ConvArgs {
     int* bn_nblk;          // host out: tiles written (0 = not fused, e.g. split-K was chosen)
     float* scratch;        // optional split-K scratch (>= 2*M*y_ld floats to be considered)
     size_t scratch_floats;
-    int force_cfg;         // -1 auto; 0: 128x128, 1: 128x64, 2: 64x64 block tile (tests/tuning)
+    int force_cfg;         // -1 auto; 0/1/2: 128x128, 128x64, 64x64 register-staged; 3/4/5: the
+                           // same tiles fed by LDS-DMA (tests/tuning)
     int force_splitk;      // 0 auto
     int splitk;            // set by the launcher
 };

@@ -21,6 +21,7 @@
 // BOTH operands, so the fmaf chain order is fixed: results are run-to-run deterministic.
 #include "common.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 namespace cilrs {
@@ -40,20 +41,28 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + (bid >> 3);
 }
 
-template <int BM, int BN, int WM, int WN, bool TAP_UNIFORM, int W_MODE>
+// DMA = true: tiles go global -> LDS directly (LDS-DMA, global_load_lds 16 B/lane), three LDS
+// stages, loads two K-tiles ahead with a COUNTED vmcnt and raw s_barrier: no VGPR round trip, no
+// ds_write, a quarter of the registers.  The LDS image is then lane-linear (128-B rows, no pad);
+// bank conflicts are avoided by XOR-swizzling the 16-B chunk index with (row>>1)&7 on the SOURCE
+// address and on the ds_read side (synthetic ladder tools/mfma_probe.hip: 104 vs 70 TF at one
+// block/CU, 123 vs 110 at three).
+template <int BM, int BN, int WM, int WN, bool TAP_UNIFORM, int W_MODE, bool DMA>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a, const int M,
                                                          const int Krow, const int KT) {
     static_assert(WM * WN == 4, "4 waves");
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
     constexpr int A_PASSES = BM / 32, B_PASSES = BN / 32;
-    constexpr int B_FLOATS = (W_MODE == 0) ? BN * APITCH : BK * (BN + 4);
-    constexpr int BPITCH1 = BN + 4;
+    constexpr int APIT = DMA ? BK : APITCH;                       // A (and k-contiguous B) pitch
+    constexpr int BPITCH1 = DMA ? BN : BN + 4;                    // W_MODE 1 (k-major B) pitch
+    constexpr int B_FLOATS = (W_MODE == 0) ? BN * APIT : BK * BPITCH1;
+    constexpr int NSTAGE = DMA ? 3 : 2;
     constexpr int JQ = BN / 4, BROWS = 256 / JQ;     // W_MODE 1 loader shape
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                       // [2][BM][APITCH]
-    float* Bs = smem + 2 * BM * APITCH;     // [2][B_FLOATS]
+    float* As = smem;                           // [NSTAGE][BM][APIT]
+    float* Bs = smem + NSTAGE * BM * APIT;      // [NSTAGE][B_FLOATS]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -76,7 +85,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a, co
 
     // ---- per-thread gather rows (fixed for the whole K loop) --------------------------------
     const int kq = tid & 7, r0 = tid >> 3;
-    long rowBase[A_PASSES];        // element offset of the row's base pixel (+ kq*4)
+    // logical 16-B chunk this thread fetches: LDS position kq of row r holds chunk kq^((r>>1)&7)
+    // when DMA (rows r0 + 32 i all share (r>>1)&7)
+    const int kql = DMA ? (kq ^ ((r0 >> 1) & 7)) : kq;
+    long rowBase[A_PASSES];        // element offset of the row's base pixel (+ kql*4)
     unsigned rowMask[A_PASSES];    // uniform path: bit t = tap t inside the image
     int rowH[A_PASSES], rowW[A_PASSES];   // generic path only
     const int HoWo = a.Ho * a.Wo;
@@ -88,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a, co
             const int n = m / HoWo, rem = m - n * HoWo;
             const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
             const int hb = oh * a.stride - a.pad, wb = ow * a.stride - a.pad;
-            rowBase[i] = ((long)(n * a.H + hb) * a.W + wb) * a.x_ld + kq * 4;
+            rowBase[i] = ((long)(n * a.H + hb) * a.W + wb) * a.x_ld + kql * 4;
             if constexpr (TAP_UNIFORM) {
                 unsigned msk = 0u;
                 for (int t = 0; t < a.ntaps; ++t) {
@@ -107,7 +119,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a, co
     const int jq = tid % JQ, kr0 = tid / JQ;
 #pragma unroll
     for (int i = 0; i < B_PASSES; ++i) {
-        if constexpr (W_MODE == 0) wBase[i] = (long)(n0 + r0 + 32 * i) * Krow + kq * 4;
+        if constexpr (W_MODE == 0) wBase[i] = (long)(n0 + r0 + 32 * i) * Krow + kql * 4;
         else wBase[i] = (long)(kr0 + BROWS * i) * wrow + n0 + jq * 4;
     }
     const int cin_tiles = TAP_UNIFORM ? (a.Cin / BK) : 1;
@@ -118,6 +130,33 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a, co
     int ld_c = kt_begin - ld_tap * cin_tiles;
     int ld_kt = kt_begin;
 
+    // DMA destinations of this wave (wave-uniform bases; lane l lands at base + 16*l bytes)
+    const int a_dst0 = (wave * 8) * BK;                              // + 32*i*BK per pass
+    const int b_dst0 = (W_MODE == 0) ? (wave * 8) * BK : (wave * (64 / JQ)) * BN;
+    int dma_stage = 0;
+    auto put_a = [&](f32x4(&ra)[A_PASSES], int i, const float* p) {
+        if constexpr (DMA) {
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)p,
+                (__attribute__((address_space(3))) void*)(As + dma_stage * BM * APIT + a_dst0 +
+                                                           32 * i * BK),
+                16, 0, 0);
+        } else {
+            ra[i] = *reinterpret_cast<const f32x4*>(p);
+        }
+    };
+    auto put_b = [&](f32x4(&rb)[B_PASSES], int i, const float* p) {
+        if constexpr (DMA) {
+            constexpr int STEP = (W_MODE == 0) ? 32 * BK : BROWS * BN;
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)p,
+                (__attribute__((address_space(3))) void*)(Bs + dma_stage * B_FLOATS + b_dst0 +
+                                                           STEP * i),
+                16, 0, 0);
+        } else {
+            rb[i] = *reinterpret_cast<const f32x4*>(p);
+        }
+    };
     auto load_tile = [&](f32x4(&ra)[A_PASSES], f32x4(&rb)[B_PASSES]) {
         if constexpr (TAP_UNIFORM) {
             const long toff = ((long)a.tap_dh[ld_tap] * a.W + a.tap_dw[ld_tap]) * a.x_ld +
@@ -126,18 +165,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a, co
             for (int i = 0; i < A_PASSES; ++i) {
                 const bool ok = (rowMask[i] >> ld_tap) & 1u;
                 const float* p = ok ? (a.x + (rowBase[i] + toff)) : zero;
-                ra[i] = *reinterpret_cast<const f32x4*>(p);
+                put_a(ra, i, p);
             }
             long koff;
             if constexpr (W_MODE == 0) koff = (long)a.tap_w[ld_tap] * a.Cin + ld_c * BK;
             else koff = (long)(ld_c * BK) * wrow + (long)a.tap_w[ld_tap] * a.w_cin;
 #pragma unroll
-            for (int i = 0; i < B_PASSES; ++i)
-                rb[i] = *reinterpret_cast<const f32x4*>(a.w + (wBase[i] + koff));
+            for (int i = 0; i < B_PASSES; ++i) put_b(rb, i, a.w + (wBase[i] + koff));
         } else {
             // generic: each k-quad may sit in a different tap (Cin % 4 == 0, e.g. the stem's
             // channel-padded Cin = 4); forward only
-            const int k = ld_kt * BK + kq * 4;
+            const int k = ld_kt * BK + kql * 4;
             const int tap = k / a.Cin, ci = k - tap * a.Cin;
             const int kh = tap / a.KW, kw = tap - kh * a.KW;
             const bool kok = k < Krow;
@@ -146,30 +184,31 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a, co
                 const int h = rowH[i] + kh, w = rowW[i] + kw;
                 const bool ok = kok && (h >= 0) && (w >= 0) && (h < a.H) && (w < a.W);
                 const float* p =
-                    ok ? (a.x + (rowBase[i] - kq * 4 + ((long)kh * a.W + kw) * a.x_ld + ci))
+                    ok ? (a.x + (rowBase[i] - kql * 4 + ((long)kh * a.W + kw) * a.x_ld + ci))
                        : zero;
-                ra[i] = *reinterpret_cast<const f32x4*>(p);
+                put_a(ra, i, p);
             }
 #pragma unroll
             for (int i = 0; i < B_PASSES; ++i) {
                 const float* p = kok ? (a.w + (wBase[i] + (long)ld_kt * BK)) : zero;
-                rb[i] = *reinterpret_cast<const f32x4*>(p);
+                put_b(rb, i, p);
             }
         }
+        if constexpr (DMA) dma_stage = (dma_stage + 1 == NSTAGE) ? 0 : dma_stage + 1;
         ++ld_kt;
         if (++ld_c == cin_tiles) { ld_c = 0; ++ld_tap; }
     };
 
     auto store_tile = [&](int buf, const f32x4(&ra)[A_PASSES], const f32x4(&rb)[B_PASSES]) {
-        float* Ab = As + buf * BM * APITCH;
+        float* Ab = As + buf * BM * APIT;
         float* Bb = Bs + buf * B_FLOATS;
 #pragma unroll
         for (int i = 0; i < A_PASSES; ++i)
-            *reinterpret_cast<f32x4*>(Ab + (r0 + 32 * i) * APITCH + kq * 4) = ra[i];
+            *reinterpret_cast<f32x4*>(Ab + (r0 + 32 * i) * APIT + kq * 4) = ra[i];
         if constexpr (W_MODE == 0) {
 #pragma unroll
             for (int i = 0; i < B_PASSES; ++i)
-                *reinterpret_cast<f32x4*>(Bb + (r0 + 32 * i) * APITCH + kq * 4) = rb[i];
+                *reinterpret_cast<f32x4*>(Bb + (r0 + 32 * i) * APIT + kq * 4) = rb[i];
         } else {
 #pragma unroll
             for (int i = 0; i < B_PASSES; ++i)
@@ -185,20 +224,22 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a, co
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    const int swz = (l31 >> 1) & 7;           // DMA: chunk swizzle of this lane's rows
     auto compute = [&](int buf) {
-        const float* Ab = As + buf * BM * APITCH + (wm * WTM + l31) * APITCH + lh * 4;
+        const float* Ab = As + buf * BM * APIT + (wm * WTM + l31) * APIT;
         const float* Bb = Bs + buf * B_FLOATS;
 #pragma unroll
         for (int q = 0; q < BK / 8; ++q) {
             f32x4 af[TM], bf[TN];
+            const int chunk = DMA ? (((2 * q + lh) ^ swz) * 4) : (q * 8 + lh * 4);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * APITCH + q * 8);
+                af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * APIT + chunk);
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 if constexpr (W_MODE == 0) {
                     bf[j] = *reinterpret_cast<const f32x4*>(
-                        Bb + (wn * WTN + j * 32 + l31) * APITCH + q * 8 + lh * 4);
+                        Bb + (wn * WTN + j * 32 + l31) * APIT + chunk);
                 } else {
                     const float* p = Bb + (q * 8 + lh * 4) * BPITCH1 + wn * WTN + j * 32 + l31;
                     bf[j][0] = p[0];
@@ -218,6 +259,25 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a, co
         }
     };
 
+    if constexpr (DMA) {
+        // ---- LDS-DMA pipeline: tile t+2 is issued while tile t is multiplied; per iteration one
+        // counted wait (this wave's loads of tile t landed) + one raw barrier (everyone's did, and
+        // everyone finished reading the stage about to be refilled)
+        constexpr int LPT = A_PASSES + B_PASSES;          // DMA instructions per wave per tile
+        f32x4 dummy_a[A_PASSES], dummy_b[B_PASSES];
+        int issued = 0;
+        for (; issued < nt && issued < 2; ++issued) load_tile(dummy_a, dummy_b);
+        int stage = 0;
+        for (int t = 0; t < nt; ++t) {
+            if (issued > t + 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (issued < nt) { load_tile(dummy_a, dummy_b); ++issued; }
+            compute(stage);
+            stage = (stage + 1 == NSTAGE) ? 0 : stage + 1;
+        }
+        __syncthreads();      // all reads done before the epilogue reuses LDS
+    } else {
     // ---- main loop: loads run two tiles ahead (register sets 0/1), LDS double-buffered ----
     f32x4 ra0[A_PASSES], rb0[B_PASSES], ra1[A_PASSES], rb1[B_PASSES];
     if (nt > 0) load_tile(ra0, rb0);
@@ -234,6 +294,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a, co
         compute(1);
         if (it + 2 < nt) store_tile(0, ra0, rb0);
         __syncthreads();
+    }
     }
 
     // ---- fused BatchNorm statistics: per-channel sum / sum of squares of this M-tile's rows
@@ -400,52 +461,65 @@ __global__ __launch_bounds__(256) void subgrid_fill_kernel(const ConvArgs a, con
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool TU, int MODE>
+template <int BM, int BN, int WM, int WN, bool TU, int MODE, bool DMA>
 int launch_cfg(const ConvArgs& a, int M, int Krow, int KT, hipStream_t s) {
-    constexpr int B_FLOATS = (MODE == 0) ? BN * APITCH : BK * (BN + 4);
-    constexpr size_t lds = (size_t)(2 * BM * APITCH + 2 * B_FLOATS) * sizeof(float);
+    constexpr int APIT = DMA ? BK : APITCH;
+    constexpr int B_FLOATS = (MODE == 0) ? BN * APIT : BK * (DMA ? BN : BN + 4);
+    constexpr int NSTAGE = DMA ? 3 : 2;
+    constexpr size_t lds = (size_t)(NSTAGE * BM * APIT + NSTAGE * B_FLOATS) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         CILRS_HIP(hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, TU, MODE>),
+            reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, WM, WN, TU, MODE, DMA>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     dim3 grid(cdiv(M, BM) * (a.Cout / BN), 1, a.splitk > 1 ? a.splitk : 1);
-    conv_igemm_kernel<BM, BN, WM, WN, TU, MODE><<<grid, 256, lds, s>>>(a, M, Krow, KT);
+    conv_igemm_kernel<BM, BN, WM, WN, TU, MODE, DMA><<<grid, 256, lds, s>>>(a, M, Krow, KT);
     CILRS_LAUNCH_CHECK();
     return 0;
 }
 
-// cost model (cycles on one CU): MFMA work of the blocks a CU executes, a latency floor per
-// K-tile when too few blocks are co-resident to hide the load-to-use latency, a fixed
-// prologue/epilogue per block, and the split-K reduce pass.
-double cfg_cost(int M, int Cout, int KT, int BM, int BN, int splitk, int occ) {
-    if (Cout % BN) return 1e30;
-    const double blocks = (double)cdiv(M, BM) * (Cout / BN) * splitk;
-    const double per_cu = (double)((long)((blocks + 255) / 256));      // blocks a CU runs
+// Cost model (microseconds).  A CU finishes b co-resident blocks of a config at the chip-wide rate
+// rate[b] (TFLOP/s, from the synthetic ladder tools/mfma_probe.hip, derated by what the real
+// kernels reach); the busiest CU runs ceil(blocks/256) blocks in groups of `occ`.
+struct Cfg { int bm, bn, occ; bool dma; float rate[4]; };
+const Cfg kCfg[6] = {
+    {128, 128, 2, false, {100.f, 113.f, 0.f, 0.f}},     // 0: register-staged 128x128
+    {128, 64, 2, false, {81.f, 100.f, 0.f, 0.f}},       // 1: register-staged 128x64
+    {64, 64, 4, false, {64.f, 90.f, 101.f, 108.f}},     // 2: register-staged 64x64
+    {128, 128, 1, true, {125.f, 0.f, 0.f, 0.f}},        // 3: LDS-DMA 128x128 (96 KB LDS)
+    {128, 64, 2, true, {110.f, 121.f, 0.f, 0.f}},       // 4: LDS-DMA 128x64  (72 KB)
+    {64, 64, 3, true, {94.f, 106.f, 111.f, 0.f}},       // 5: LDS-DMA 64x64   (48 KB)
+};
+constexpr int kNumCfg = 6;
+
+double cfg_cost(int M, int Cout, int KT, const Cfg& c, int splitk) {
+    if (Cout % c.bn) return 1e30;
+    const double blocks = (double)cdiv(M, c.bm) * (Cout / c.bn) * splitk;
+    const long per_cu = (long)((blocks + 255) / 256);
     const double ktiles = (double)cdiv(KT, splitk);
-    const double mfma = (double)BM * BN / 4.0;                          // cycles per K-tile
-    const double conc = per_cu < occ ? per_cu : occ;                    // co-resident blocks
-    const double lat = 2600.0;                                          // per K-tile, one block
-    const double t_mfma = per_cu * ktiles * mfma * (BM * BN >= 128 * 128 ? 1.12 : 1.0);
-    const double t_lat = (per_cu / conc) * ktiles * (lat + mfma * 0.25);
-    double cost = (t_mfma > t_lat ? t_mfma : t_lat) + per_cu / conc * 9000.0;
-    if (splitk > 1) cost += 4000.0 + (double)M * Cout * (splitk + 1) / 256.0 / 24.0;
-    return cost;
+    const double unit = 2.0 * c.bm * c.bn * BK * ktiles;               // flops per block
+    const long full = per_cu / c.occ, rem = per_cu % c.occ;
+    double t = 0.0;
+    if (full) t += full * unit * 256.0 * c.occ / (c.rate[c.occ - 1] * 1e6);
+    if (rem) t += unit * 256.0 * rem / (c.rate[rem - 1] * 1e6);
+    t += (full + (rem ? 1 : 0)) * 2.5;                                   // fill / drain per group
+    if (splitk > 1) t += 3.0 + (double)M * Cout * 4.0 * (splitk + 1) / 3.0e6;
+    return t;
 }
 
 struct Choice { int cfg; int splitk; };
-const int kBM[3] = {128, 128, 64};
-const int kBN[3] = {128, 64, 64};
-const int kOcc[3] = {2, 2, 4};
 
 Choice choose(int M, int Cout, int KT, bool allow_split, int force_cfg, int force_splitk) {
     static const int splits[11] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48};
+    static const int use_dma = getenv("CILRS_IGEMM_DMA") ? atoi(getenv("CILRS_IGEMM_DMA")) : 0;
     Choice best{2, 1};
     double bc = 1e30;
-    for (int c = 0; c < 3; ++c) {
+    for (int c = 0; c < kNumCfg; ++c) {
         if (force_cfg >= 0 && c != force_cfg) continue;
+        if (force_cfg < 0 && use_dma == 0 && kCfg[c].dma) continue;
+        if (force_cfg < 0 && use_dma == 2 && !kCfg[c].dma) continue;
         for (int si = 0; si < 11; ++si) {
             int sk = splits[si];
             if (force_splitk > 0) {
@@ -454,7 +528,7 @@ Choice choose(int M, int Cout, int KT, bool allow_split, int force_cfg, int forc
             } else if (sk > 1 && (!allow_split || KT < 2 * sk)) {
                 continue;
             }
-            const double cost = cfg_cost(M, Cout, KT, kBM[c], kBN[c], sk, kOcc[c]);
+            const double cost = cfg_cost(M, Cout, KT, kCfg[c], sk);
             if (cost < bc) { bc = cost; best = {c, sk}; }
         }
     }
@@ -500,23 +574,28 @@ int launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
     Choice ch = choose(M, a.Cout, KT, can_split, a.force_cfg, a.force_splitk);
     while (ch.splitk > 1 && (size_t)ch.splitk * slab > a.scratch_floats) --ch.splitk;
     CILRS_CHECK(ch.splitk == 1 || (a.scratch && uniform), "conv_igemm: split-K needs scratch");
-    CILRS_CHECK(ch.cfg >= 0 && ch.cfg < 3 && a.Cout % kBN[ch.cfg] == 0,
+    CILRS_CHECK(ch.cfg >= 0 && ch.cfg < kNumCfg && a.Cout % kCfg[ch.cfg].bn == 0,
                 "conv_igemm: tile config %d does not fit Cout=%d", ch.cfg, a.Cout);
     a.splitk = ch.splitk;
-    if (a_in.bn_nblk) *a_in.bn_nblk = (a.bn_partial && a.splitk == 1) ? cdiv(M, kBM[ch.cfg]) : 0;
+    if (a_in.bn_nblk) *a_in.bn_nblk = (a.bn_partial && a.splitk == 1) ? cdiv(M, kCfg[ch.cfg].bm) : 0;
     float* final_y = a.y;
     if (a.splitk > 1) a.y = a.scratch;
 
     int rc = 1;
-#define CILRS_DISPATCH(BM_, BN_)                                                         \
-    do {                                                                                 \
-        if (a.w_mode == 1) rc = launch_cfg<BM_, BN_, 2, 2, true, 1>(a, M, Krow, KT, s);  \
-        else if (uniform)  rc = launch_cfg<BM_, BN_, 2, 2, true, 0>(a, M, Krow, KT, s);  \
-        else               rc = launch_cfg<BM_, BN_, 2, 2, false, 0>(a, M, Krow, KT, s); \
+#define CILRS_DISPATCH(BM_, BN_, DMA_)                                                          \
+    do {                                                                                        \
+        if (a.w_mode == 1) rc = launch_cfg<BM_, BN_, 2, 2, true, 1, DMA_>(a, M, Krow, KT, s);   \
+        else if (uniform)  rc = launch_cfg<BM_, BN_, 2, 2, true, 0, DMA_>(a, M, Krow, KT, s);   \
+        else               rc = launch_cfg<BM_, BN_, 2, 2, false, 0, DMA_>(a, M, Krow, KT, s);  \
     } while (0)
-    if (ch.cfg == 0) CILRS_DISPATCH(128, 128);
-    else if (ch.cfg == 1) CILRS_DISPATCH(128, 64);
-    else CILRS_DISPATCH(64, 64);
+    switch (ch.cfg) {
+        case 0: CILRS_DISPATCH(128, 128, false); break;
+        case 1: CILRS_DISPATCH(128, 64, false); break;
+        case 2: CILRS_DISPATCH(64, 64, false); break;
+        case 3: CILRS_DISPATCH(128, 128, true); break;
+        case 4: CILRS_DISPATCH(128, 64, true); break;
+        default: CILRS_DISPATCH(64, 64, true); break;
+    }
 #undef CILRS_DISPATCH
     if (rc) return rc;
 

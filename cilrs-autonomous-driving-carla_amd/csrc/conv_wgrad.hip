@@ -217,36 +217,60 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slabs, f
 
 struct WPlan { int bt; bool uniform; int tiles_ci; int ntiles; int ncols; int splits; };
 
+// Tile and split choice.  The output (Cout x taps*Cin) is tiny next to K = N*Ho*Wo, so K must be
+// split across blocks; every split costs a slab written and read back.  Model (microseconds):
+// the busiest CU runs ceil(blocks/256) blocks in co-resident groups at the rates measured by
+// tools/mfma_probe.hip (derated), plus the slab traffic and the reduce launch.
+double wplan_cost(double flops, int tiles, int splits, int bt, size_t out_floats) {
+    static const float r128[2] = {105.f, 120.f};                 // 2 blocks/CU fit (67 KB LDS)
+    static const float r64[4] = {60.f, 85.f, 96.f, 103.f};       // 4 blocks/CU fit (35 KB LDS)
+    const int occ = bt == 128 ? 2 : 4;
+    const float* rate = bt == 128 ? r128 : r64;
+    const long blocks = (long)tiles * splits;
+    const long per_cu = (blocks + 255) / 256;
+    const double unit = flops / (double)blocks;                  // flops per block
+    const long full = per_cu / occ, rem = per_cu % occ;
+    double t = 0.0;
+    if (full) t += full * unit * 256.0 * occ / (rate[occ - 1] * 1e6);
+    if (rem) t += unit * 256.0 * rem / (rate[rem - 1] * 1e6);
+    t += (full + (rem ? 1 : 0)) * 3.0;
+    t += 4.0 + (double)out_floats * 4.0 * (2.0 * splits + 1.0) / 3.5e6;   // slabs out + back
+    return t;
+}
+
 WPlan plan(const WgradArgs& a) {
-    WPlan p;
+    WPlan best;
     const int taps = a.KH * a.KW;
     const int Mpix = a.N * a.Ho * a.Wo;
-    p.ncols = taps * a.Cin;
-    p.uniform = (a.Cin % 64) == 0;
-    p.bt = (p.uniform && a.Cin % 128 == 0 && a.Cout % 128 == 0) ? 128 : 64;
+    const int KT = cdiv(Mpix, BKP);
+    const bool uniform = (a.Cin % 64) == 0;
+    const size_t out_floats = (size_t)a.Cout * taps * a.Cin;
+    const double flops = 2.0 * Mpix * (double)out_floats;
     static const int env_bt = getenv("CILRS_WGRAD_BT") ? atoi(getenv("CILRS_WGRAD_BT")) : 0;
     static const int env_target = getenv("CILRS_WGRAD_TARGET") ? atoi(getenv("CILRS_WGRAD_TARGET")) : 0;
-    if (env_bt == 64) p.bt = 64;
-    if (p.uniform) {
-        p.tiles_ci = a.Cin / p.bt;
-        p.ntiles = taps * p.tiles_ci;
-    } else {
-        p.tiles_ci = 1;
-        p.ntiles = cdiv(p.ncols, p.bt);
+    double bc = 1e30;
+    for (int bt = 64; bt <= 128; bt += 64) {
+        if (bt == 128 && !(uniform && a.Cin % 128 == 0 && a.Cout % 128 == 0)) continue;
+        if (env_bt && bt != env_bt) continue;
+        WPlan p;
+        p.bt = bt; p.uniform = uniform; p.ncols = taps * a.Cin;
+        if (uniform) { p.tiles_ci = a.Cin / bt; p.ntiles = taps * p.tiles_ci; }
+        else { p.tiles_ci = 1; p.ntiles = cdiv(p.ncols, bt); }
+        const int tiles = p.ntiles * (a.Cout / bt);
+        const int max_splits = KT / 4 > 0 ? KT / 4 : 1;
+        // candidate block budgets: whole numbers of blocks per CU
+        for (int budget = 256; budget <= 2048; budget += 256) {
+            if (env_target && budget != ((env_target + 255) / 256) * 256) continue;
+            int splits = budget / tiles;
+            if (splits < 1) splits = 1;
+            if (splits > max_splits) splits = max_splits;
+            const int per = cdiv(KT, splits);
+            splits = cdiv(KT, per);                  // drop empty trailing splits
+            const double c = wplan_cost(flops, tiles, splits, bt, out_floats);
+            if (c < bc) { bc = c; best = p; best.splits = splits; }
+        }
     }
-    const int tiles = p.ntiles * (a.Cout / p.bt);
-    const int KT = cdiv(Mpix, BKP);
-    int target = 768;      // measured best over 256..1536 on the trunk shapes (tools/wgrad_sweep.sh)
-    if (env_target > 0) target = env_target;
-    int splits = cdiv(target, tiles);
-    const int max_splits = KT / 8 > 0 ? KT / 8 : 1;
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
-    // drop empty trailing splits
-    const int per = cdiv(KT, splits);
-    splits = cdiv(KT, per);
-    p.splits = splits;
-    return p;
+    return best;
 }
 
 }  // namespace

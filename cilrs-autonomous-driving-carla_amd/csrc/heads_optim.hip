@@ -70,11 +70,38 @@ __global__ void pad_cin3_to_4_kernel(const float* __restrict__ w3, float* __rest
     *reinterpret_cast<f32x4*>(w4 + i * 4) = v;
 }
 
-// ---- narrow linear layers (in = 1, out = 3, out = 1): one thread per output element ------------
+// ---- narrow linear layers (in = 1, out = 3, out = 1) ---------------------------------------------
+// in >= 64: one wave per sample row, lanes split K (coalesced), shuffle tree per output (<= 4);
+// otherwise one thread per output element.
 __global__ __launch_bounds__(256) void linear_small_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
     float* __restrict__ y, const int B, const int in, const int out, const int x_ld,
     const int y_ld, const int relu) {
+    if (in >= 64 && out <= 4) {
+        const int lane = threadIdx.x & 63;
+        const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+        if (b >= B) return;
+        const float* xr = x + (size_t)b * x_ld;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int k = lane; k < in; k += 64) {
+            const float xv = xr[k];
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+                if (o < out) acc[o] = fmaf(xv, w[(size_t)o * in + k], acc[o]);
+        }
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            float v = acc[o];
+#pragma unroll
+            for (int sft = 32; sft > 0; sft >>= 1) v += __shfl_xor(v, sft);
+            if (lane == 0 && o < out) {
+                v += bias[o];
+                if (relu) v = fmaxf(v, 0.f);
+                y[(size_t)b * y_ld + o] = v;
+            }
+        }
+        return;
+    }
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * out) return;
     const int b = i / out, o = i - b * out;
@@ -109,28 +136,53 @@ __global__ __launch_bounds__(256) void linear_small_bwd_dw_kernel(
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < out * in) {
         const int o = i / in, k = i - o * in;
-        float acc = 0.f;
-        for (int b = 0; b < B; ++b)
-            acc = fmaf(dy[(size_t)b * dy_ld + o], x[(size_t)b * x_ld + k], acc);
+        float a4[4] = {0.f, 0.f, 0.f, 0.f};
+        int b = 0;
+        for (; b + 3 < B; b += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                a4[u] = fmaf(dy[(size_t)(b + u) * dy_ld + o], x[(size_t)(b + u) * x_ld + k], a4[u]);
+        }
+        for (; b < B; ++b) a4[0] = fmaf(dy[(size_t)b * dy_ld + o], x[(size_t)b * x_ld + k], a4[0]);
+        const float acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
         dw[i] = accumulate ? dw[i] + acc : acc;
     } else if (i < out * in + out) {
         const int o = i - out * in;
-        float acc = 0.f;
-        for (int b = 0; b < B; ++b) acc += dy[(size_t)b * dy_ld + o];
+        float a4[4] = {0.f, 0.f, 0.f, 0.f};
+        int b = 0;
+        for (; b + 3 < B; b += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a4[u] += dy[(size_t)(b + u) * dy_ld + o];
+        }
+        for (; b < B; ++b) a4[0] += dy[(size_t)b * dy_ld + o];
+        const float acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
         db[o] = accumulate ? db[o] + acc : acc;
     }
 }
 
-// db[o] = sum_b dy[b][o] for the wide layers
+// db[o] = sum_b dy[b][o] for the wide layers: 64 columns x 4 row groups per block
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dy,
                                                      float* __restrict__ db, const int B,
                                                      const int out, const int dy_ld,
                                                      const int accumulate) {
-    const int o = blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= out) return;
-    float acc = 0.f;
-    for (int b = 0; b < B; ++b) acc += dy[(size_t)b * dy_ld + o];
-    db[o] = accumulate ? db[o] + acc : acc;
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int o = blockIdx.x * 64 + cl;
+    float a4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (o < out) {
+        int b = g;
+        for (; b + 12 < B; b += 16) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a4[u] += dy[(size_t)(b + 4 * u) * dy_ld + o];
+        }
+        for (; b < B; b += 4) a4[0] += dy[(size_t)b * dy_ld + o];
+    }
+    red[g][cl] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+    __syncthreads();
+    if (g == 0 && o < out) {
+        const float acc = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+        db[o] = accumulate ? db[o] + acc : acc;
+    }
 }
 
 // d[b][c] = act[b][c] > 0 ? d[b][c]*scale : 0
@@ -369,8 +421,8 @@ int launch_pad_cin3_to_4(const float* w3, float* w4, int n_taps_total, hipStream
 
 int launch_linear_small_fwd(const float* x, const float* w, const float* bias, float* y, int B,
                             int in, int out, int x_ld, int y_ld, int relu, hipStream_t s) {
-    linear_small_fwd_kernel<<<cdiv(B * out, 256), 256, 0, s>>>(x, w, bias, y, B, in, out, x_ld,
-                                                               y_ld, relu);
+    const int blocks = (in >= 64 && out <= 4) ? cdiv(B, 4) : cdiv(B * out, 256);
+    linear_small_fwd_kernel<<<blocks, 256, 0, s>>>(x, w, bias, y, B, in, out, x_ld, y_ld, relu);
     CILRS_LAUNCH_CHECK();
     return 0;
 }
@@ -395,7 +447,7 @@ int launch_linear_small_bwd(const float* dy, const float* x, const float* w, con
 
 int launch_colsum(const float* dy, float* db, int B, int out, int dy_ld, int accumulate,
                   hipStream_t s) {
-    colsum_kernel<<<cdiv(out, 256), 256, 0, s>>>(dy, db, B, out, dy_ld, accumulate);
+    colsum_kernel<<<cdiv(out, 64), 256, 0, s>>>(dy, db, B, out, dy_ld, accumulate);
     CILRS_LAUNCH_CHECK();
     return 0;
 }

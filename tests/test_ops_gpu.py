@@ -51,12 +51,13 @@ def _tol(ref, scale=2e-5):
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-@pytest.mark.parametrize("cfg,splitk", [(-1, 0), (0, 1), (1, 1), (2, 1), (1, 3), (2, 2)])
+@pytest.mark.parametrize("cfg,splitk", [(-1, 0), (0, 1), (1, 1), (2, 1), (1, 3), (2, 2),
+                                        (3, 1), (4, 1), (5, 1), (5, 2), (4, 3)])
 def test_conv_fwd(case, cfg, splitk):
     L = _lib()
     lib = L.lib()
     N, H, W, Cin, Cout, k, s, p = case
-    if cfg == 0 and Cout % 128:
+    if cfg in (0, 3) and Cout % 128:
         pytest.skip("128-wide tile needs Cout % 128 == 0")
     g = torch.Generator().manual_seed(1)
     x = torch.randn(N, Cin, H, W, generator=g)
@@ -89,15 +90,18 @@ def test_conv_fwd_stem():
     w4[..., :3] = w.permute(0, 2, 3, 1)
     y = torch.full((N, 44, 100, 64), float("nan"), device="cuda")
     x4d, w4d = dev(x4), dev(w4)          # keep alive: ptr() does not hold a reference
-    L.check(lib.cilrs_conv2d_fwd(L.ptr(x4d), L.ptr(w4d), L.ptr(y), N, H, W, 4, 64, 7, 7,
-                                 2, 3, -1, 0, None, 0, stream()))
-    torch.cuda.synchronize()
-    got = y.cpu().permute(0, 3, 1, 2)
-    assert (got - ref).abs().max() <= _tol(ref)
+    for cfg in (-1, 1, 2, 4, 5):
+        y.fill_(float("nan"))
+        L.check(lib.cilrs_conv2d_fwd(L.ptr(x4d), L.ptr(w4d), L.ptr(y), N, H, W, 4, 64, 7, 7,
+                                     2, 3, cfg, 0, None, 0, stream()))
+        torch.cuda.synchronize()
+        got = y.cpu().permute(0, 3, 1, 2)
+        assert (got - ref).abs().max() <= _tol(ref), cfg
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-@pytest.mark.parametrize("cfg,splitk,with_addend", [(-1, 0, False), (1, 1, True), (2, 2, True)])
+@pytest.mark.parametrize("cfg,splitk,with_addend", [(-1, 0, False), (1, 1, True), (2, 2, True),
+                                                    (4, 1, True), (5, 2, False), (5, 1, True)])
 def test_conv_dgrad(case, cfg, splitk, with_addend):
     L = _lib()
     lib = L.lib()

@@ -56,9 +56,9 @@ def main():
                           device="cuda")
         flops = 2.0 * N * Ho * Wo * Cout * k * k * Cin
         res = []
-        fwd_cfgs = [] if args.wgrad_only else [(-1, 0), (0, 1), (1, 1), (2, 1), (0, 2), (1, 2), (2, 2), (0, 3), (1, 3), (2, 3)]
+        fwd_cfgs = [] if args.wgrad_only else [(-1, 0), (0, 1), (1, 1), (2, 1), (2, 2), (0, 3), (3, 1), (4, 1), (5, 1), (3, 2), (4, 2), (5, 2), (3, 4), (4, 4), (5, 3)]
         for cfg, sk in fwd_cfgs:
-            if cfg == 0 and Cout % 128:
+            if cfg in (0, 3) and Cout % 128:
                 continue
 
             def f():
@@ -66,8 +66,8 @@ def main():
                                              k, s, p, cfg, sk, L.ptr(scratch), scratch.numel(), st))
             us = timeit(f, args.iters)
             res.append(f"fwd[c{cfg},k{sk}] {us:7.1f}us {flops / us / 1e6:6.1f}TF")
-        for cfg, sk in ([] if args.wgrad_only else [(-1, 0), (0, 1), (1, 1), (2, 1), (1, 2), (2, 2)]):
-            if cfg == 0 and Cin % 128:
+        for cfg, sk in ([] if args.wgrad_only else [(-1, 0), (1, 1), (2, 1), (2, 2), (3, 1), (4, 1), (5, 1), (4, 2), (5, 2)]):
+            if cfg in (0, 3) and Cin % 128:
                 continue
 
             def f():
