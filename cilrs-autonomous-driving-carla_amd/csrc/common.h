@@ -83,6 +83,8 @@ struct ConvArgs {
     float* bn_partial;     // optional: per-M-tile column sums / sums of squares of the raw output,
                            // [tile][2][Cout] (BatchNorm batch statistics fused into the conv)
     int* bn_nblk;          // host out: tiles written (0 = not fused, e.g. split-K was chosen)
+    int* tile_counters;    // optional: zeroed ticket counters (one per output tile) for the
+    int tile_counters_cap; //   in-kernel split-K reduction; NULL => carved from `scratch`
     float* scratch;        // optional split-K scratch (>= 2*M*y_ld floats to be considered)
     size_t scratch_floats;
     int force_cfg;         // -1 auto; 0/1/2: 128x128, 128x64, 64x64 register-staged; 3/4/5: the
@@ -100,6 +102,7 @@ struct DgradArgs {
     int N, H, W, Cin, Ho, Wo, Cout, K, stride, pad;
     int dy_ld, dx_ld;
     float* scratch; size_t scratch_floats; int force_cfg, force_splitk;
+    int* tile_counters; int tile_counters_cap;     // see ConvArgs
 };
 int launch_conv_dgrad(const DgradArgs& a, hipStream_t s);
 

@@ -297,9 +297,71 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a, co
     }
     }
 
+    // ---- split-K: every K-slice block parks its partial tile in a slab; the block that draws the
+    // last ticket of the tile sums the slabs in slice order (deterministic) and runs the epilogue.
+    // Publish / acquire follow cdna_hip_programming.md "In-launch split-K reduction": plain slab
+    // stores -> every wave drains vmcnt -> barrier -> one lane: agent release fence, drain,
+    // relaxed agent-scope ticket; the last arriver: agent acquire fence, drain, barrier, plain loads.
+    bool inkernel_reduce = false;
+    if (a.splitk > 1 && a.tile_counters != nullptr) {
+        inkernel_reduce = true;
+        float* slab = a.scratch + (size_t)blockIdx.z * M * a.y_ld;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int co = n0 + wn * WTN + j * 32 + l31;
+                const int mbase = m0 + wm * WTM + i * 32 + 4 * lh;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mbase + (r & 3) + 8 * (r >> 2);
+                    if (m < M) slab[(size_t)m * a.y_ld + co] = acc[i][j][r];
+                }
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        volatile int* flag = reinterpret_cast<volatile int*>(smem);
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int prev = __hip_atomic_fetch_add(&a.tile_counters[logical], 1, __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_AGENT);
+            const int last = (prev == a.splitk - 1) ? 1 : 0;
+            if (last) {
+                // leave the counter ready for the next launch; nobody else touches it any more
+                __hip_atomic_store(&a.tile_counters[logical], 0, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            flag[0] = last;
+        }
+        __syncthreads();
+        const int is_last = flag[0];
+        __syncthreads();                         // flag word is reused as scratch below
+        if (!is_last) return;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int co = n0 + wn * WTN + j * 32 + l31;
+                const int mbase = m0 + wm * WTM + i * 32 + 4 * lh;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                for (int z = 0; z < a.splitk; ++z) {
+                    const float* sl = a.scratch + (size_t)z * M * a.y_ld;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = mbase + (r & 3) + 8 * (r >> 2);
+                        if (m < M) acc[i][j][r] += sl[(size_t)m * a.y_ld + co];
+                    }
+                }
+            }
+    }
+
     // ---- fused BatchNorm statistics: per-channel sum / sum of squares of this M-tile's rows
     // (rows >= M are exact zeros).  Fixed summation order => deterministic.
-    if (a.bn_partial != nullptr && a.splitk <= 1) {
+    if (a.bn_partial != nullptr && (a.splitk <= 1 || inkernel_reduce)) {
         float* red = smem;                       // [WM][BN][2]; the K loop ended on a barrier
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -336,7 +398,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a, co
     // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     // Optional operands are fetched as 16 independent loads per tile (clamped row, no per-element
     // branch) so their latency overlaps instead of serialising.
-    const bool partial = a.splitk > 1;
+    const bool partial = a.splitk > 1 && !inkernel_reduce;
     const bool dense = (a.out_sh == 1) && (a.out_sw == 1) && (a.out_H == a.Ho) &&
                        (a.out_W == a.Wo);
     float* yout = partial ? a.y + (size_t)blockIdx.z * M * a.y_ld : a.y;
@@ -505,7 +567,7 @@ double cfg_cost(int M, int Cout, int KT, const Cfg& c, int splitk) {
     if (full) t += full * unit * 256.0 * c.occ / (c.rate[c.occ - 1] * 1e6);
     if (rem) t += unit * 256.0 * rem / (c.rate[rem - 1] * 1e6);
     t += (full + (rem ? 1 : 0)) * 2.5;                                   // fill / drain per group
-    if (splitk > 1) t += 3.0 + (double)M * Cout * 4.0 * (splitk + 1) / 3.0e6;
+    if (splitk > 1) t += 3.0 + (double)M * Cout * 4.0 * (splitk + 1) / 3.0e6;    // slabs + reduce
     return t;
 }
 
@@ -577,9 +639,36 @@ int launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
     CILRS_CHECK(ch.cfg >= 0 && ch.cfg < kNumCfg && a.Cout % kCfg[ch.cfg].bn == 0,
                 "conv_igemm: tile config %d does not fit Cout=%d", ch.cfg, a.Cout);
     a.splitk = ch.splitk;
-    if (a_in.bn_nblk) *a_in.bn_nblk = (a.bn_partial && a.splitk == 1) ? cdiv(M, kCfg[ch.cfg].bm) : 0;
+    // in-kernel reduction needs one ticket counter per output tile (zero before the launch; the
+    // last arriver re-zeroes it).  Counters live at the head of the scratch unless given.
+    const int n_tiles = cdiv(M, kCfg[ch.cfg].bm) * (a.Cout / kCfg[ch.cfg].bn);
+    // Measured (profiles/, r01): the agent-scope release every slice block must execute costs more
+    // than the separate reduce launch it saves (train step +9 %, B=1 inference 2.6x), so the
+    // in-kernel path is opt-in (CILRS_SPLITK_INKERNEL=1); the default is slabs + reduce kernel.
+    static const int inkernel_on =
+        getenv("CILRS_SPLITK_INKERNEL") ? atoi(getenv("CILRS_SPLITK_INKERNEL")) : 0;
+    bool inkernel = false;
+    if (!inkernel_on) a.tile_counters = nullptr;
+    if (a.splitk > 1 && inkernel_on) {
+        if (a.tile_counters == nullptr) {
+            // carve [counters | slabs] out of the caller's scratch and zero the counters
+            const size_t cnt_floats = ((size_t)n_tiles + 63) / 64 * 64;
+            if (a.scratch_floats >= cnt_floats + (size_t)a.splitk * slab) {
+                a.tile_counters = reinterpret_cast<int*>(a.scratch);
+                CILRS_HIP(hipMemsetAsync(a.tile_counters, 0, cnt_floats * sizeof(float), s));
+                a.scratch += cnt_floats;
+                a.scratch_floats -= cnt_floats;
+                inkernel = true;
+            }
+        } else {
+            inkernel = n_tiles <= a.tile_counters_cap;
+            if (!inkernel) a.tile_counters = nullptr;
+        }
+    }
+    if (a_in.bn_nblk)
+        *a_in.bn_nblk = (a.bn_partial && (a.splitk == 1 || inkernel)) ? cdiv(M, kCfg[ch.cfg].bm) : 0;
     float* final_y = a.y;
-    if (a.splitk > 1) a.y = a.scratch;
+    if (a.splitk > 1 && !inkernel) a.y = a.scratch;      // legacy: partials + separate reduce
 
     int rc = 1;
 #define CILRS_DISPATCH(BM_, BN_, DMA_)                                                          \
@@ -599,7 +688,7 @@ int launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
 #undef CILRS_DISPATCH
     if (rc) return rc;
 
-    if (a.splitk > 1) {
+    if (a.splitk > 1 && !inkernel) {
         const float* part = a.scratch;
         a.y = final_y;
         const size_t total = (size_t)M * (a.Cout / 4);
@@ -623,6 +712,7 @@ int launch_conv_dgrad(const DgradArgs& d, hipStream_t s) {
     a.x_ld = d.dy_ld; a.y_ld = d.dx_ld; a.w_mode = 1; a.w_cin = d.Cin;
     a.scratch = d.scratch; a.scratch_floats = d.scratch_floats;
     a.force_cfg = d.force_cfg; a.force_splitk = d.force_splitk;
+    a.tile_counters = d.tile_counters; a.tile_counters_cap = d.tile_counters_cap;
     if (d.stride == 1) {
         a.Ho = d.H; a.Wo = d.W; a.stride = 1; a.pad = d.K - 1 - d.pad;
         return launch_conv_igemm(a, s);           // dense table with flipped taps

@@ -207,6 +207,7 @@ using namespace cilrs;
 // The plan
 // ------------------------------------------------------------------------------------------------
 struct ConvG { int H, W, Ho, Wo, M; size_t y, z, stats; };
+constexpr int kTileCounters = 16384, kHeadCounters = 1024;
 
 struct cilrs_net {
     int B, H, W;
@@ -218,6 +219,8 @@ struct cilrs_net {
     size_t dcombined, ds1, dp1, dp2, dh1[4], dh2[4], dcomb_part[5], d_all, speed_in,
         cmd_b /*bytes offset*/;
     size_t hscr[5], hscr_floats, hslab[5], hslab_floats;   // per-chain scratch of the heads
+    size_t tile_cnt, hcnt[5];              // split-K ticket counters (ints; trunk / head chains)
+    const void* cnt_zeroed_for = nullptr;  // workspace whose counters have been zeroed
     size_t G[5];                           // rotating gradient buffers (max activation size)
     size_t gmax;
     size_t bn_partial, bn_coef, slabs, slabs_floats, ksplit, ksplit_floats, status_b;
@@ -272,6 +275,17 @@ struct Bump {
             if (CALL_) return 1;                                                      \
         }                                                                             \
     } while (0)
+
+// split-K ticket counters start at zero; every reducer block re-zeroes its own afterwards
+int zero_counters_once(cilrs_net* net, void* workspace, hipStream_t s) {
+    if (net->cnt_zeroed_for == workspace) return 0;
+    float* ws = reinterpret_cast<float*>(workspace);
+    CILRS_HIP(hipMemsetAsync(ws + net->tile_cnt, 0, kTileCounters * sizeof(int), s));
+    for (int k = 0; k < 5; ++k)
+        CILRS_HIP(hipMemsetAsync(ws + net->hcnt[k], 0, kHeadCounters * sizeof(int), s));
+    net->cnt_zeroed_for = workspace;
+    return 0;
+}
 
 int ensure_streams(cilrs_net* net) {
     if (net->streams_ready) return 0;
@@ -350,6 +364,8 @@ int conv_fwd(cilrs_net* net, const ConvT& c, const ConvG& g, const float* x, int
     a.KH = a.KW = c.k; a.stride = c.stride; a.pad = c.pad;
     a.x_ld = x_cin; a.y_ld = c.cout; a.w_mode = 0; a.w_cin = x_cin;
     a.scratch = ws + net->ksplit; a.scratch_floats = net->ksplit_floats;
+    a.tile_counters = reinterpret_cast<int*>(ws + net->tile_cnt);
+    a.tile_counters_cap = kTileCounters;
     a.force_cfg = -1;
     if (bn_nblk) { a.bn_partial = ws + net->bn_partial; a.bn_nblk = bn_nblk; *bn_nblk = 0; }
     const double flops = 2.0 * g.M * c.cout * c.k * c.k * c.cin;
@@ -370,6 +386,8 @@ int conv_dgrad(cilrs_net* net, const ConvT& c, const ConvG& g, const float* dy, 
     a.Ho = g.Ho; a.Wo = g.Wo; a.Cout = c.cout; a.K = c.k; a.stride = c.stride; a.pad = c.pad;
     a.dy_ld = c.cout; a.dx_ld = c.cin;
     a.scratch = ws + net->ksplit; a.scratch_floats = net->ksplit_floats;
+    a.tile_counters = reinterpret_cast<int*>(ws + net->tile_cnt);
+    a.tile_counters_cap = kTileCounters;
     a.force_cfg = -1;
     const double flops = 2.0 * g.M * c.cout * c.k * c.k * c.cin;
     const double bytes = 4.0 * ((double)net->B * g.H * g.W * c.cin + (double)g.M * c.cout +
@@ -407,6 +425,8 @@ int lin_fwd(cilrs_net* net, const LinT& l, const float* P, const float* x, int x
     a.KH = a.KW = 1; a.stride = 1; a.pad = 0;
     a.x_ld = x_ld; a.y_ld = y_ld; a.w_mode = 0; a.w_cin = l.in; a.relu = relu;
     a.scratch = net->ws_base + net->hscr[chain]; a.scratch_floats = net->hscr_floats;
+    a.tile_counters = reinterpret_cast<int*>(net->ws_base + net->hcnt[chain]);
+    a.tile_counters_cap = kHeadCounters;
     a.force_cfg = -1;
     RUN(net, "heads_fwd", 2.0 * net->B * l.in * l.out, 4.0 * l.in * l.out, s,
         launch_conv_igemm(a, s));
@@ -425,6 +445,8 @@ int lin_dgrad(cilrs_net* net, const LinT& l, const float* P, const float* dy, in
     a.K = 1; a.stride = 1; a.pad = 0;
     a.dy_ld = dy_ld; a.dx_ld = dx_ld;
     a.scratch = net->ws_base + net->hscr[chain]; a.scratch_floats = net->hscr_floats;
+    a.tile_counters = reinterpret_cast<int*>(net->ws_base + net->hcnt[chain]);
+    a.tile_counters_cap = kHeadCounters;
     a.force_cfg = -1;
     RUN(net, "heads_bwd", 2.0 * net->B * l.in * l.out, 4.0 * l.in * l.out, s,
         launch_conv_dgrad(a, s));
@@ -627,6 +649,8 @@ int cilrs_net_create(int batch, int height, int width, cilrs_net** out) {
     n->ksplit_floats = ksplit_max;
     n->ksplit = bump.take(ksplit_max > 0 ? ksplit_max : 4);
     n->status_b = bump.take(64) * sizeof(float);
+    n->tile_cnt = bump.take(kTileCounters);
+    for (int k = 0; k < 5; ++k) n->hcnt[k] = bump.take(kHeadCounters);
     n->bn_table.n = (int)A.convs.size();
     for (size_t ci = 0; ci < A.convs.size(); ++ci) {
         const BnT& b = A.bns[A.convs[ci].bn];
@@ -663,6 +687,7 @@ static int forward_from_x4(cilrs_net* net, const cilrs_buffers* bufs, const floa
     const Arch& A = arch();
     float* ws = reinterpret_cast<float*>(bufs->workspace);
     net->ws_base = ws;
+    if (zero_counters_once(net, bufs->workspace, s)) return 1;
     const float* P = bufs->params;
     float* R = bufs->bn_running;
     const int B = net->B;
