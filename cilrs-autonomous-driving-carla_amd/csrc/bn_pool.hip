@@ -458,13 +458,17 @@ int launch_bn_eval_fwd(const float* y, int M, int C, const float* gamma, const f
 int launch_bn_bwd(const float* dz, const float* z, const float* y, int M, int C,
                   const float* gamma, const float* stats, int relu, float* dgamma, float* dbeta,
                   int accumulate, float* coef, float* partial, float* dy, float* g_out,
-                  hipStream_t s) {
+                  int pre_nblk, hipStream_t s) {
     if (check_c(C)) return 1;
-    const ColPlan p = col_plan(M, C);
-    bn_colreduce_kernel<1><<<p.nblk, 256, 0, s>>>(y, dz, z, stats, partial, M, C, relu,
-                                                  p.rows_per_block);
-    CILRS_LAUNCH_CHECK();
-    bn_bwd_finalize_kernel<<<cdiv(C, 32), 1024, 0, s>>>(partial, p.nblk, M, C, gamma, stats,
+    int nblk = pre_nblk;
+    if (nblk <= 0) {
+        const ColPlan p = col_plan(M, C);
+        bn_colreduce_kernel<1><<<p.nblk, 256, 0, s>>>(y, dz, z, stats, partial, M, C, relu,
+                                                      p.rows_per_block);
+        CILRS_LAUNCH_CHECK();
+        nblk = p.nblk;
+    }
+    bn_bwd_finalize_kernel<<<cdiv(C, 32), 1024, 0, s>>>(partial, nblk, M, C, gamma, stats,
                                                         dgamma, dbeta, coef, accumulate);
     CILRS_LAUNCH_CHECK();
     const size_t total4 = (size_t)M * C / 4;

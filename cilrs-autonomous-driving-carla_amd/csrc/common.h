@@ -83,6 +83,10 @@ struct ConvArgs {
     float* bn_partial;     // optional: per-M-tile column sums / sums of squares of the raw output,
                            // [tile][2][Cout] (BatchNorm batch statistics fused into the conv)
     int* bn_nblk;          // host out: tiles written (0 = not fused, e.g. split-K was chosen)
+    // optional: BatchNorm-backward reductions of the layer this (data-gradient) output feeds,
+    // fused into the epilogue: per M-tile [2][Cout] partial sums of g and g*xhat
+    const float* bwd_z; const float* bwd_y; const float* bwd_stats; int bwd_relu;
+    float* bwd_partial; int* bwd_nblk;     // host out: tiles written (0 = not fused)
     int* tile_counters;    // optional: zeroed ticket counters (one per output tile) for the
     int tile_counters_cap; //   in-kernel split-K reduction; NULL => carved from `scratch`
     float* scratch;        // optional split-K scratch (>= 2*M*y_ld floats to be considered)
@@ -103,6 +107,8 @@ struct DgradArgs {
     int dy_ld, dx_ld;
     float* scratch; size_t scratch_floats; int force_cfg, force_splitk;
     int* tile_counters; int tile_counters_cap;     // see ConvArgs
+    const float* bwd_z; const float* bwd_y; const float* bwd_stats; int bwd_relu;
+    float* bwd_partial; int* bwd_nblk;
 };
 int launch_conv_dgrad(const DgradArgs& a, hipStream_t s);
 
@@ -143,10 +149,11 @@ int launch_bn_eval_stats_all(const BnEvalTable& t, const float* params, const fl
 int launch_bn_eval_fwd(const float* y, int M, int C, const float* gamma, const float* beta,
                        const float* running_mean, const float* running_var, float eps,
                        const float* residual, int relu, float* stats, float* z, hipStream_t s);
+// pre_nblk > 0: `partial` already holds pre_nblk per-tile partial sums (fused into the dgrad)
 int launch_bn_bwd(const float* dz, const float* z, const float* y, int M, int C,
                   const float* gamma, const float* stats, int relu, float* dgamma, float* dbeta,
                   int accumulate, float* coef, float* partial, float* dy, float* g_out,
-                  hipStream_t s);
+                  int pre_nblk, hipStream_t s);
 int launch_maxpool_fwd(const float* x, float* out, unsigned char* argmax, int N, int H, int W,
                        int C, hipStream_t s);
 int launch_maxpool_bwd(const float* dout, const unsigned char* argmax, float* dx, int N, int H,

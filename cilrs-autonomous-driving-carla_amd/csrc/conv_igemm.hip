@@ -402,6 +402,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a, co
     const bool dense = (a.out_sh == 1) && (a.out_sw == 1) && (a.out_H == a.Ho) &&
                        (a.out_W == a.Wo);
     float* yout = partial ? a.y + (size_t)blockIdx.z * M * a.y_ld : a.y;
+    // fused BatchNorm-backward reductions of the layer this data gradient feeds: per channel
+    // sum(g) and sum(g * xhat), g = dz * (z > 0), xhat = (y - mean) * rstd
+    const bool bwd_red = a.bwd_partial != nullptr && !partial;
+    float bs1[TN], bs2[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { bs1[j] = 0.f; bs2[j] = 0.f; }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -458,11 +464,52 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a, co
                     for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
                 }
             }
+            if (bwd_red) {
+                float zz[16], yy[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    zz[r] = a.bwd_relu ? a.bwd_z[(size_t)pix[r] * a.y_ld + co] : 1.f;
+                    yy[r] = a.bwd_y[(size_t)pix[r] * a.y_ld + co];
+                }
+                const float mean = a.bwd_stats[co], rstd = a.bwd_stats[a.Cout + co];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mbase + (r & 3) + 8 * (r >> 2);
+                    const float g = (m < M && zz[r] > 0.f) ? v[r] : 0.f;
+                    bs1[j] += g;
+                    bs2[j] = fmaf(g, (yy[r] - mean) * rstd, bs2[j]);
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = mbase + (r & 3) + 8 * (r >> 2);
                 if (m < M) yout[(size_t)pix[r] * a.y_ld + co] = v[r];
             }
+        }
+    }
+    if (bwd_red) {
+        __syncthreads();                          // LDS may still hold the forward-stats scratch
+        float* red = smem;                        // [WM][BN][2]
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float s1 = bs1[j] + __shfl_xor(bs1[j], 32);
+            float s2 = bs2[j] + __shfl_xor(bs2[j], 32);
+            if (lh == 0) {
+                red[(wm * BN + wn * WTN + j * 32 + l31) * 2] = s1;
+                red[(wm * BN + wn * WTN + j * 32 + l31) * 2 + 1] = s2;
+            }
+        }
+        __syncthreads();
+        if (tid < BN) {
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) {
+                t1 += red[(w * BN + tid) * 2];
+                t2 += red[(w * BN + tid) * 2 + 1];
+            }
+            const size_t mt = (size_t)(logical / tilesN);
+            a.bwd_partial[mt * 2 * a.Cout + n0 + tid] = t1;
+            a.bwd_partial[mt * 2 * a.Cout + a.Cout + n0 + tid] = t2;
         }
     }
 }
@@ -667,6 +714,9 @@ int launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
     }
     if (a_in.bn_nblk)
         *a_in.bn_nblk = (a.bn_partial && (a.splitk == 1 || inkernel)) ? cdiv(M, kCfg[ch.cfg].bm) : 0;
+    const bool dense_out = a.out_sh == 1 && a.out_sw == 1 && a.out_H == a.Ho && a.out_W == a.Wo;
+    if (!(a.splitk == 1 && dense_out)) a.bwd_partial = nullptr;
+    if (a_in.bwd_nblk) *a_in.bwd_nblk = a.bwd_partial ? cdiv(M, kCfg[ch.cfg].bm) : 0;
     float* final_y = a.y;
     if (a.splitk > 1 && !inkernel) a.y = a.scratch;      // legacy: partials + separate reduce
 
@@ -713,7 +763,10 @@ int launch_conv_dgrad(const DgradArgs& d, hipStream_t s) {
     a.scratch = d.scratch; a.scratch_floats = d.scratch_floats;
     a.force_cfg = d.force_cfg; a.force_splitk = d.force_splitk;
     a.tile_counters = d.tile_counters; a.tile_counters_cap = d.tile_counters_cap;
+    if (d.bwd_nblk) *d.bwd_nblk = 0;
     if (d.stride == 1) {
+        a.bwd_z = d.bwd_z; a.bwd_y = d.bwd_y; a.bwd_stats = d.bwd_stats; a.bwd_relu = d.bwd_relu;
+        a.bwd_partial = d.bwd_partial; a.bwd_nblk = d.bwd_nblk;
         a.Ho = d.H; a.Wo = d.W; a.stride = 1; a.pad = d.K - 1 - d.pad;
         return launch_conv_igemm(a, s);           // dense table with flipped taps
     }

@@ -234,6 +234,7 @@ struct cilrs_net {
     hipEvent_t fork_ev, join_ev[5], gbuf_ev[5];
     bool gbuf_pending[5] = {false, false, false, false, false};
     int dy_toggle = 0;
+    int bwd_nblk_next = 0;                 // fused BN-backward partials waiting for their BN
     BnEvalTable bn_table;
     // cached hipGraph of the uint8 inference path (fixed pointers)
     hipGraphExec_t graph_exec = nullptr;
@@ -378,10 +379,16 @@ int conv_fwd(cilrs_net* net, const ConvT& c, const ConvG& g, const float* x, int
 
 // dx[B,H,W,cin] (+= addend) from dy[B,Ho,Wo,cout]
 int conv_dgrad(cilrs_net* net, const ConvT& c, const ConvG& g, const float* dy, const float* w,
-               float* dx, const float* addend, float* ws, hipStream_t s) {
+               float* dx, const float* addend, float* ws, hipStream_t s,
+               const ConvG* bn_of = nullptr, int bn_relu = 1, int* bwd_nblk = nullptr) {
     DgradArgs a;
     memset(&a, 0, sizeof(a));
     a.dy = dy; a.w = w; a.dx = dx; a.addend = addend;
+    if (bn_of && bwd_nblk) {       // the BatchNorm layer whose output gradient this call produces
+        a.bwd_z = ws + bn_of->z; a.bwd_y = ws + bn_of->y; a.bwd_stats = ws + bn_of->stats;
+        a.bwd_relu = bn_relu; a.bwd_partial = ws + net->bn_partial; a.bwd_nblk = bwd_nblk;
+        *bwd_nblk = 0;
+    }
     a.N = net->B; a.H = g.H; a.W = g.W; a.Cin = c.cin;
     a.Ho = g.Ho; a.Wo = g.Wo; a.Cout = c.cout; a.K = c.k; a.stride = c.stride; a.pad = c.pad;
     a.dy_ld = c.cout; a.dx_ld = c.cin;
@@ -946,6 +953,7 @@ int cilrs_net_backward(cilrs_net* net, const cilrs_buffers* bufs, const float* d
     for (int seg = seg_begin; seg < seg_end; ++seg) {
         if (seg == 0) {
             CILRS_CHECK(dcontrols && dpred_speed, "backward: output gradients missing");
+            net->bwd_nblk_next = 0;
             if (backward_heads(net, bufs, dcontrols, dpred_speed, nullptr, s)) return 1;
             // d visual -> avgpool backward -> grad of the last block's output, in G[3]
             RUN(net, "heads_bwd", 0.0, 0.0, s,
@@ -991,11 +999,15 @@ int cilrs_net_backward(cilrs_net* net, const cilrs_buffers* bufs, const float* d
                 RUN(net, "bn_bwd." + grp, 0.0, 4.0 * g2.M * c2.cout * 8.0, s,
                     launch_bn_bwd(Gd, ws + g2.z, ws + g2.y, g2.M, c2.cout, P + b2.gamma,
                                   ws + g2.stats, 1, Gp + b2.gamma, Gp + b2.beta, 0,
-                                  ws + net->bn_coef, ws + net->bn_partial, Ga, Gb, s));
+                                  ws + net->bn_coef, ws + net->bn_partial, Ga, Gb,
+                                  net->bwd_nblk_next, s));
+                net->bwd_nblk_next = 0;
                 // 2./3. conv2: dW2 (side), da -> Gc
                 if (wgrad_side(c2, g2, ws + g1.z, ga, Gp + c2.w)) return 1;
                 if (gbuf_acquire(net, s, 2)) return 1;
-                if (conv_dgrad(net, c2, g2, Ga, P + c2.w, Gc, nullptr, ws, s)) return 1;
+                int nb1 = 0;        // BN1's reductions ride on this dgrad's epilogue
+                if (conv_dgrad(net, c2, g2, Ga, P + c2.w, Gc, nullptr, ws, s, &g1, 1, &nb1))
+                    return 1;
                 // 4. a = relu(bn1(y1)): dy1 -> the other dy buffer
                 ga = net->dy_toggle ? 4 : 0;
                 net->dy_toggle ^= 1;
@@ -1004,12 +1016,15 @@ int cilrs_net_backward(cilrs_net* net, const cilrs_buffers* bufs, const float* d
                 RUN(net, "bn_bwd." + grp, 0.0, 4.0 * g1.M * c1.cout * 7.0, s,
                     launch_bn_bwd(Gc, ws + g1.z, ws + g1.y, g1.M, c1.cout, P + b1.gamma,
                                   ws + g1.stats, 1, Gp + b1.gamma, Gp + b1.beta, 0,
-                                  ws + net->bn_coef, ws + net->bn_partial, Ga, nullptr, s));
+                                  ws + net->bn_coef, ws + net->bn_partial, Ga, nullptr, nb1, s));
                 // 5. dW1 (side)
                 if (wgrad_side(c1, g1, xin, ga, Gp + c1.w)) return 1;
                 if (blk.down < 0) {
                     // 6. dx = dgrad(conv1) + identity grad (Gb) -> Gd
-                    if (conv_dgrad(net, c1, g1, Ga, P + c1.w, Gd, Gb, ws, s)) return 1;
+                    // ... and carries the reductions of the previous block's bn2
+                    const ConvG* prev = bi > 0 ? &net->cg[A.blocks[bi - 1].conv2] : nullptr;
+                    if (conv_dgrad(net, c1, g1, Ga, P + c1.w, Gd, Gb, ws, s, prev, 1,
+                                   &net->bwd_nblk_next)) return 1;
                 } else {
                     const ConvT& cd = A.convs[blk.down];
                     const ConvG& gd = net->cg[blk.down];
@@ -1020,7 +1035,7 @@ int cilrs_net_backward(cilrs_net* net, const cilrs_buffers* bufs, const float* d
                     RUN(net, "bn_bwd." + grp, 0.0, 4.0 * gd.M * cd.cout * 6.0, s,
                         launch_bn_bwd(Gb, nullptr, ws + gd.y, gd.M, cd.cout, P + bd.gamma,
                                       ws + gd.stats, 0, Gp + bd.gamma, Gp + bd.beta, 0,
-                                      ws + net->bn_coef, ws + net->bn_partial, Gc, nullptr, s));
+                                      ws + net->bn_coef, ws + net->bn_partial, Gc, nullptr, 0, s));
                     if (wgrad_side(cd, gd, xin, 2, Gp + cd.w)) return 1;
                     // 8. dx += dgrad(conv_d)
                     if (conv_dgrad(net, cd, gd, Gc, P + cd.w, Gd, Gd, ws, s)) return 1;
@@ -1043,7 +1058,7 @@ int cilrs_net_backward(cilrs_net* net, const cilrs_buffers* bufs, const float* d
             RUN(net, "bn_bwd.stem", 0.0, 4.0 * g0.M * 64 * 7.0, s,
                 launch_bn_bwd(ws + net->G[0], ws + g0.z, ws + g0.y, g0.M, 64, P + b0.gamma,
                               ws + g0.stats, 1, Gp + b0.gamma, Gp + b0.beta, 0, ws + net->bn_coef,
-                              ws + net->bn_partial, ws + net->G[1], nullptr, s));
+                              ws + net->bn_partial, ws + net->G[1], nullptr, 0, s));
             if (conv_wgrad(net, c0, g0, ws + net->x4, 4, ws + net->G[1], Gp + c0.w, ws, s))
                 return 1;
         }
@@ -1266,7 +1281,7 @@ int cilrs_bn_bwd(const float* dz, const float* z, const float* y, int M, int C,
                  const float* gamma, const float* stats, int relu, float* dgamma, float* dbeta,
                  float* coef3c, float* partial, float* dy, float* g_out, void* stream) {
     return launch_bn_bwd(dz, z, y, M, C, gamma, stats, relu, dgamma, dbeta, 0, coef3c, partial, dy,
-                         g_out, reinterpret_cast<hipStream_t>(stream));
+                         g_out, 0, reinterpret_cast<hipStream_t>(stream));
 }
 int cilrs_maxpool_fwd(const float* x, float* out, uint8_t* argmax, int N, int H, int W, int C,
                       void* stream) {
