@@ -13,6 +13,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -300,7 +301,12 @@ int ensure_streams(cilrs_net* net) {
     return 0;
 }
 // concurrency is switched off while per-kernel timing is on (serial brackets are meaningful)
-bool use_overlap(cilrs_net* net) { return net->overlap && !net->prof.on; }
+bool use_overlap(cilrs_net* net) {
+    // CILRS_OVERLAP=0 serialises everything on the caller's stream (rocprofv3 per-kernel durations
+    // then match the hipEvent brackets of the profile mode)
+    static const int env = getenv("CILRS_OVERLAP") ? atoi(getenv("CILRS_OVERLAP")) : 1;
+    return env != 0 && net->overlap && !net->prof.on;
+}
 // side streams [0,n) start after everything enqueued on `main` so far
 int fork_streams(cilrs_net* net, hipStream_t main, int n) {
     if (!use_overlap(net)) return 0;
