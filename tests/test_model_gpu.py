@@ -348,3 +348,32 @@ def test_batched_eval_matches_oracle():
         c, s = m(*to_dev(img, spd, cmd))
     assert (c.cpu() - oc).abs().max() <= TOL_OUT
     assert (s.cpu() - os_).abs().max() <= TOL_OUT
+
+
+@pytest.mark.parametrize("B,H,W", [(3, 96, 160), (2, 90, 202), (1, 88, 200), (5, 64, 64)])
+def test_other_geometries_forward_and_step(B, H, W):
+    """The plan is geometry-generic (odd pooling edges, tiny feature maps, B=1 batch statistics):
+    eval forward and one fused train step vs the oracle."""
+    from cilrs_mi355 import CONFIG_A, Trainer
+    g = torch.Generator().manual_seed(B * 1000 + H)
+    img = torch.randn(B, 3, H, W, generator=g)
+    spd = torch.rand(B, generator=g)
+    cmd = torch.randint(0, 4, (B,), generator=g)
+    tgt = torch.rand(B, 3, generator=g)
+    m = make_model().eval()
+    orc = O.build_oracle(0).eval()
+    with torch.no_grad():
+        oc, os_ = orc(img, spd, cmd)
+        c, s = m(*to_dev(img, spd, cmd))
+    assert (c.cpu() - oc).abs().max() <= TOL_OUT
+    assert (s.cpu() - os_).abs().max() <= TOL_OUT
+    if B == 1 and H * W < 100 * 100:
+        return
+    tr = Trainer(m, CONFIG_A)
+    tr.train_step(*to_dev(img, spd, cmd, tgt))
+    ld, _ = O.train_step(orc, O.make_optimizer(orc, O.CONFIG_A), O.CONFIG_A, img, spd, cmd, tgt)
+    got = tr.losses()
+    for k in ld:
+        assert abs(got[k] - ld[k]) <= 1e-4 * max(1.0, abs(ld[k])), (k, got[k], ld[k])
+    for (n, a), (_, b) in zip(m.named_parameters(), orc.named_parameters()):
+        _close_params(a.detach().cpu(), b.detach(), CONFIG_A.lr, 1)
