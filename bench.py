@@ -246,13 +246,11 @@ def main():
         pl1 = trainer.eng.plan(1, 88, 200)
         pl1.profile_reset()
         pl1.profile(True)
-        pr.use_graph = False
         for _ in range(10):
             pr.predict_controls(frame, 25.0, 0)
         torch.cuda.synchronize(dev)
         t1 = pl1.profile_table()
         pl1.profile(False)
-        pr.use_graph = True
         out["infer_device_us"] = {k: round(v["ms"] / 10 * 1e3, 1)
                                   for k, v in sorted(t1.items(), key=lambda kv: -kv[1]["ms"])}
         out["infer_device_us"]["total"] = round(sum(v["ms"] for v in t1.values()) / 10 * 1e3, 1)

@@ -19,9 +19,12 @@ SPEED_NORM_FACTOR = 90.0               # :485
 
 class Predictor:
     """Holds pinned staging buffers so a 20 Hz control loop does one H2D and one D2H copy per
-    tick (the reference does four ``.item()`` syncs, :918-920)."""
+    tick (the reference does four ``.item()`` syncs, :918-920).  ``use_graph=True`` replays the
+    forward from a cached hipGraph; measured on MI355X the eager launch sequence is as fast
+    (0.69 vs 0.76 ms device time at B=1: the path is bound by ~75 dependent small kernels, not by
+    host launch overhead), so it is off by default."""
 
-    def __init__(self, model, batch=1, height=IMG_HEIGHT, width=IMG_WIDTH, use_graph=True):
+    def __init__(self, model, batch=1, height=IMG_HEIGHT, width=IMG_WIDTH, use_graph=False):
         self.model = model.eval()
         self.eng = model.engine()
         dev = self.eng.device
@@ -30,14 +33,19 @@ class Predictor:
         self.stream = torch.cuda.Stream(device=dev)      # hipGraph capture needs its own stream
         self.ctrl_dev = torch.empty(batch, 3, dtype=torch.float32, device=dev)
         self.spd_out_dev = torch.empty(batch, dtype=torch.float32, device=dev)
-        self.out_dev = torch.empty(batch, 4, dtype=torch.float32, device=dev)
+        self.ctrl_host = torch.empty(batch, 3, dtype=torch.float32).pin_memory()
+        self.spd_out_host = torch.empty(batch, dtype=torch.float32).pin_memory()
+        self._ctrl_np = self.ctrl_host.numpy()
+        self._spd_np = self.spd_out_host.numpy()
         self.frames_host = torch.empty(batch, height, width, 3, dtype=torch.uint8).pin_memory()
         self.frames_dev = torch.empty(batch, height, width, 3, dtype=torch.uint8, device=dev)
         self.speed_host = torch.empty(batch, dtype=torch.float32).pin_memory()
         self.cmd_host = torch.empty(batch, dtype=torch.int64).pin_memory()
         self.speed_dev = torch.empty(batch, dtype=torch.float32, device=dev)
         self.cmd_dev = torch.empty(batch, dtype=torch.int64, device=dev)
-        self.out_host = torch.empty(batch, 4, dtype=torch.float32).pin_memory()
+        self._frames_np = self.frames_host.numpy()
+        self._speed_np = self.speed_host.numpy()
+        self._cmd_np = self.cmd_host.numpy()
 
     @torch.no_grad()
     def predict_batch(self, frames_u8, speeds_kmh, commands):
@@ -48,24 +56,32 @@ class Predictor:
                           self.frames_host.size(2), self.use_graph)
         if self.model.training:
             self.model.eval()
-        self.frames_host.copy_(torch.as_tensor(frames_u8))
-        sp = np.minimum(np.asarray(speeds_kmh, dtype=np.float32) / np.float32(SPEED_NORM_FACTOR),
-                        np.float32(1.0))
-        self.speed_host.copy_(torch.from_numpy(sp))
-        self.cmd_host.copy_(torch.as_tensor(commands, dtype=torch.int64))
+        # host staging through NUMPY views of the pinned buffers: torch CPU ops would wake the
+        # intra-op thread pool, whose spinning workers exhaust a container's CPU quota and stall
+        # the control loop for ~90 ms every ~200 ms (measured: tools/stall_probe2.py)
+        np.copyto(self._frames_np, np.asarray(frames_u8, dtype=np.uint8))
+        # min(speed_kmh / 90.0, 1.0) in double like the reference (:910), then float32
+        self._speed_np[...] = np.minimum(
+            np.asarray(speeds_kmh, dtype=np.float64) / SPEED_NORM_FACTOR, 1.0)
+        np.copyto(self._cmd_np, np.asarray(commands, dtype=np.int64))
         with torch.cuda.stream(self.stream):
             self.frames_dev.copy_(self.frames_host, non_blocking=True)
             self.speed_dev.copy_(self.speed_host, non_blocking=True)
             self.cmd_dev.copy_(self.cmd_host, non_blocking=True)
             self.eng.run_forward_u8(self.frames_dev, self.speed_dev, self.cmd_dev,
                                     out=(self.ctrl_dev, self.spd_out_dev), graph=self.use_graph)
-            self.out_dev[:, :3].copy_(self.ctrl_dev)
-            torch.mul(self.spd_out_dev, SPEED_NORM_FACTOR, out=self.out_dev[:, 3])
-            self.out_host.copy_(self.out_dev, non_blocking=True)
+            # two tiny D2H copies into pinned memory; no torch kernels, no allocations
+            self.ctrl_host.copy_(self.ctrl_dev, non_blocking=True)
+            self.spd_out_host.copy_(self.spd_out_dev, non_blocking=True)
             self.stream.synchronize()
-        return self.out_host.numpy().copy()
+        out = np.empty((self.batch, 4), dtype=np.float32)
+        out[:, :3] = self._ctrl_np
+        out[:, 3] = self._spd_np * np.float32(SPEED_NORM_FACTOR)                # :920
+        return out
 
     def predict_controls(self, image_rgb_u8, speed_kmh, command_idx):
         """Same return tuple as the reference's predict_controls (:918-920)."""
         r = self.predict_batch(np.asarray(image_rgb_u8)[None], [speed_kmh], [command_idx])[0]
-        return float(r[0]), float(r[1]), float(r[2]), float(r[3])
+        # the reference multiplies the float32 .item() by 90.0 in Python (double)
+        return (float(r[0]), float(r[1]), float(r[2]),
+                float(self._spd_np[0]) * SPEED_NORM_FACTOR)

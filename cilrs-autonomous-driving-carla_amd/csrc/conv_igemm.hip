@@ -520,10 +520,13 @@ __device__ __forceinline__ int out_pixel(const ConvArgs& a, int m, int HoWo) {
     return (n * a.out_H + oh * a.out_sh + a.out_h0) * a.out_W + ow * a.out_sw + a.out_w0;
 }
 
-// Sum split-K partials (fixed order => deterministic) and apply the epilogue.
+// Sum split-K partials (fixed order => deterministic) and apply the epilogue.  VEC = 4: one float4
+// per thread; VEC = 1: one float per thread (small problems: 4x the threads).  Four independent
+// load streams over the splits.
+template <int VEC>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvArgs a, const float* part,
                                                             const int M, const int splits) {
-    const int cq = a.Cout >> 2;
+    const int cq = a.Cout / VEC;
     const size_t total = (size_t)M * cq;
     const size_t slab = (size_t)M * a.y_ld;
     const int HoWo = a.Ho * a.Wo;
@@ -532,14 +535,40 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvArgs a, co
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (size_t)gridDim.x * blockDim.x) {
         const int m = (int)(idx / cq);
-        const int co = (int)(idx - (size_t)m * cq) * 4;
+        const int co = (int)(idx - (size_t)m * cq) * VEC;
         const size_t o = (size_t)m * a.y_ld + co;
-        f32x4 v = *reinterpret_cast<const f32x4*>(part + o);
-        for (int s = 1; s < splits; ++s) v += *reinterpret_cast<const f32x4*>(part + s * slab + o);
+        float v[VEC];
+        {
+            float acc[4][VEC];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[u][e] = 0.f;
+            int sidx = 0;
+            for (; sidx + 3 < splits; sidx += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if constexpr (VEC == 4) {
+                        const f32x4 t =
+                            *reinterpret_cast<const f32x4*>(part + (size_t)(sidx + u) * slab + o);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[u][e] += t[e];
+                    } else {
+                        acc[u][0] += part[(size_t)(sidx + u) * slab + o];
+                    }
+                }
+            }
+            for (; sidx < splits; ++sidx) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[0][e] += part[(size_t)sidx * slab + o + e];
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[e] = (acc[0][e] + acc[1][e]) + (acc[2][e] + acc[3][e]);
+        }
         const int pix = dense ? m : out_pixel(a, m, HoWo);
         const size_t po = (size_t)pix * a.y_ld + co;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < VEC; ++e) {
             float t = v[e];
             if (a.ch_scale) t = t * a.ch_scale[co + e] + a.ch_shift[co + e];
             if (a.bias) t += a.bias[co + e];
@@ -550,7 +579,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvArgs a, co
             if (a.relu_post) t = fmaxf(t, 0.f);
             v[e] = t;
         }
-        *reinterpret_cast<f32x4*>(a.y + po) = v;
+        if constexpr (VEC == 4) {
+            f32x4 ov = {v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(a.y + po) = ov;
+        } else {
+            a.y[po] = v[0];
+        }
     }
 }
 
@@ -614,7 +648,7 @@ double cfg_cost(int M, int Cout, int KT, const Cfg& c, int splitk) {
     if (full) t += full * unit * 256.0 * c.occ / (c.rate[c.occ - 1] * 1e6);
     if (rem) t += unit * 256.0 * rem / (c.rate[rem - 1] * 1e6);
     t += (full + (rem ? 1 : 0)) * 2.5;                                   // fill / drain per group
-    if (splitk > 1) t += 3.0 + (double)M * Cout * 4.0 * (splitk + 1) / 3.0e6;    // slabs + reduce
+    if (splitk > 1) t += 3.0 + 0.12 * splitk + (double)M * Cout * 4.0 * (splitk + 1) / 3.0e6;  // slabs + reduce
     return t;
 }
 
@@ -741,9 +775,14 @@ int launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
     if (a.splitk > 1 && !inkernel) {
         const float* part = a.scratch;
         a.y = final_y;
-        const size_t total = (size_t)M * (a.Cout / 4);
-        const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-        splitk_reduce_kernel<<<blocks, 256, 0, s>>>(a, part, M, a.splitk);
+        const size_t total4 = (size_t)M * (a.Cout / 4);
+        if (total4 < 65536) {        // small problem: one float per thread, 4x the parallelism
+            const size_t total = total4 * 4;
+            splitk_reduce_kernel<1><<<(int)((total + 255) / 256), 256, 0, s>>>(a, part, M, a.splitk);
+        } else {
+            const int blocks = (int)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);
+            splitk_reduce_kernel<4><<<blocks, 256, 0, s>>>(a, part, M, a.splitk);
+        }
         CILRS_LAUNCH_CHECK();
     }
     return 0;

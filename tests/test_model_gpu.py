@@ -377,3 +377,15 @@ def test_other_geometries_forward_and_step(B, H, W):
         assert abs(got[k] - ld[k]) <= 1e-4 * max(1.0, abs(ld[k])), (k, got[k], ld[k])
     for (n, a), (_, b) in zip(m.named_parameters(), orc.named_parameters()):
         _close_params(a.detach().cpu(), b.detach(), CONFIG_A.lr, 1)
+
+
+def test_predictor_graph_replay_matches_eager():
+    """The hipGraph replay of the uint8 inference path returns exactly the eager results."""
+    from cilrs_mi355.predict import Predictor
+    m = make_model()
+    frame = np.floor(O._hash_u01(7, 3, 88 * 200 * 3) * 256).astype(np.uint8).reshape(88, 200, 3)
+    eager = Predictor(m, use_graph=False)
+    a = [eager.predict_controls(frame, 30.0 + i, i % 4) for i in range(4)]
+    graph = Predictor(m, use_graph=True)
+    b = [graph.predict_controls(frame, 30.0 + i, i % 4) for i in range(4)]
+    assert a == b
