@@ -45,6 +45,8 @@ SIGNATURES = {
     "cilrs_net_forward": (i32, [vp, C.POINTER(Buffers), vp, C.c_long, C.c_long, C.c_long,
                                 C.c_long, vp, vp, i32, f32, u64, vp, vp, vp]),
     "cilrs_net_forward_u8": (i32, [vp, C.POINTER(Buffers), vp, vp, vp, vp, vp, vp]),
+    "cilrs_net_forward_camera": (i32, [vp, C.POINTER(Buffers), vp, i32, i32, i32, C.c_long,
+                                       C.c_long, vp, vp, vp, vp, vp]),
     "cilrs_net_forward_u8_graph": (i32, [vp, C.POINTER(Buffers), vp, vp, vp, vp, vp, vp]),
     "cilrs_loss_fwd_bwd": (i32, [vp, vp, vp, vp, i32, i32, c_float_p, f32, vp, vp, vp, vp]),
     "cilrs_net_backward": (i32, [vp, C.POINTER(Buffers), vp, vp, i32, i32, vp]),
@@ -53,6 +55,8 @@ SIGNATURES = {
     "cilrs_grad_sqnorm": (i32, [vp, sz, f32, vp, vp, vp]),
     "cilrs_adam_step": (i32, [vp, vp, vp, vp, sz, f64, f64, f64, f64, f64, i64, vp, f32, vp]),
     "cilrs_scale": (i32, [vp, sz, vp, f32, vp]),
+    "cilrs_eval_acc_doubles": (i32, []),
+    "cilrs_eval_accumulate": (i32, [vp, vp, vp, vp, vp, i32, vp, vp, vp]),
     "cilrs_net_profile_enable": (i32, [vp, i32]),
     "cilrs_net_profile_collect": (i32, [vp]),
     "cilrs_net_profile_count": (i32, [vp]),

@@ -234,6 +234,26 @@ class Engine:
                    L.ptr(pred_speed), self._stream()))
         return controls, pred_speed
 
+    def run_forward_camera(self, frames_u8, speed, command, height=88, width=200, out=None):
+        """Raw camera frames uint8 [B,Hs,Ws,3|4] (device) -> eval forward with the whole of
+        preprocess_image fused: bilinear resize to (height, width), /255, normalise."""
+        if frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4 or frames_u8.size(3) not in (3, 4):
+            raise RuntimeError("camera frames must be uint8 [B,Hs,Ws,3 or 4]")
+        b = frames_u8.size(0)
+        pl = self.plan(b, height, width)
+        frames_u8 = frames_u8.contiguous()
+        if out is None:
+            controls = torch.empty(b, 3, dtype=torch.float32, device=self.device)
+            pred_speed = torch.empty(b, dtype=torch.float32, device=self.device)
+        else:
+            controls, pred_speed = out
+        hs, ws, px = frames_u8.size(1), frames_u8.size(2), frames_u8.size(3)
+        L.check(L.lib().cilrs_net_forward_camera(
+            pl.handle, C.byref(self.bufs[(pl.batch, pl.h, pl.w)]), L.ptr(frames_u8), hs, ws, px,
+            ws * px, hs * ws * px, L.ptr(speed.contiguous()), L.ptr(command.contiguous()),
+            L.ptr(controls), L.ptr(pred_speed), self._stream()))
+        return controls, pred_speed
+
     def run_backward(self, pl, dcontrols, dpred_speed, seg_begin=0, seg_end=6):
         L.check(L.lib().cilrs_net_backward(
             pl.handle, C.byref(self.bufs[(pl.batch, pl.h, pl.w)]), L.ptr(dcontrols),

@@ -1,10 +1,12 @@
 """Inference adapter -- counterpart of AutonomousDriver.preprocess_image / predict_controls
 (reference model/autonomous_drive.py:481-485, 897-920).
 
-The reference resizes the 800x600 camera frame with cv2.resize (INTER_LINEAR) on the host; cv2 is
-not part of this engine, so frames are expected at the network resolution (88x200) already.  The
-/255, HWC->CHW and Normalize(mean, std) steps are fused into one HIP kernel that writes the NHWC
-tensor the stem convolution reads.
+Frames at the network resolution (88x200) take the uint8 path: /255, HWC->CHW and
+Normalize(mean, std) fused into one HIP kernel that writes the NHWC tensor the stem reads.  Frames
+of any other size (the agent's camera is 800x600, 4 bytes per pixel, :868-872) take the camera
+path, which also fuses the reference's host-side cv2.resize (8-bit INTER_LINEAR, restated from
+OpenCV's published fixed-point algorithm -- cv2 is not in the build image, so that step is
+parity-unpinned) into the same kernel: the whole of preprocess_image runs on the device.
 """
 from __future__ import annotations
 
@@ -79,9 +81,48 @@ class Predictor:
         out[:, 3] = self._spd_np * np.float32(SPEED_NORM_FACTOR)                # :920
         return out
 
+    @torch.no_grad()
+    def predict_camera(self, frame_u8, speed_kmh, command_idx):
+        """One raw camera frame uint8 [Hs,Ws,3|4] -> (steer, throttle, brake, speed_kmh); the
+        resize happens on the device (preprocess_image, :897-902)."""
+        if self.batch != 1:
+            raise RuntimeError("predict_camera is the single-frame control-loop path")
+        frame = np.asarray(frame_u8, dtype=np.uint8)
+        if frame.ndim != 3 or frame.shape[2] not in (3, 4):
+            raise RuntimeError("camera frame must be uint8 [Hs,Ws,3 or 4]")
+        if self.model.engine() is not self.eng:
+            self.__init__(self.model, self.batch, self.frames_host.size(1),
+                          self.frames_host.size(2), self.use_graph)
+        if self.model.training:
+            self.model.eval()
+        cam = getattr(self, "_cam", None)
+        if cam is None or cam[0].shape[1:] != frame.shape:
+            host = torch.empty((1,) + frame.shape, dtype=torch.uint8).pin_memory()
+            cam = (host, host.numpy(), torch.empty_like(host, device=self.eng.device))
+            self._cam = cam
+        np.copyto(cam[1][0], frame)
+        self._speed_np[...] = min(float(speed_kmh) / SPEED_NORM_FACTOR, 1.0)
+        self._cmd_np[...] = int(command_idx)
+        with torch.cuda.stream(self.stream):
+            cam[2].copy_(cam[0], non_blocking=True)
+            self.speed_dev.copy_(self.speed_host, non_blocking=True)
+            self.cmd_dev.copy_(self.cmd_host, non_blocking=True)
+            self.eng.run_forward_camera(cam[2], self.speed_dev, self.cmd_dev,
+                                        self.frames_host.size(1), self.frames_host.size(2),
+                                        out=(self.ctrl_dev, self.spd_out_dev))
+            self.ctrl_host.copy_(self.ctrl_dev, non_blocking=True)
+            self.spd_out_host.copy_(self.spd_out_dev, non_blocking=True)
+            self.stream.synchronize()
+        c = self._ctrl_np[0]
+        return (float(c[0]), float(c[1]), float(c[2]), float(self._spd_np[0]) * SPEED_NORM_FACTOR)
+
     def predict_controls(self, image_rgb_u8, speed_kmh, command_idx):
-        """Same return tuple as the reference's predict_controls (:918-920)."""
-        r = self.predict_batch(np.asarray(image_rgb_u8)[None], [speed_kmh], [command_idx])[0]
+        """Same return tuple as the reference's predict_controls (:918-920).  Frames that are not
+        already 88x200x3 go through the fused resize (predict_camera)."""
+        image_rgb_u8 = np.asarray(image_rgb_u8)
+        if image_rgb_u8.shape != tuple(self.frames_host.shape[1:]):
+            return self.predict_camera(image_rgb_u8, speed_kmh, command_idx)
+        r = self.predict_batch(image_rgb_u8[None], [speed_kmh], [command_idx])[0]
         # the reference multiplies the float32 .item() by 90.0 in Python (double)
         return (float(r[0]), float(r[1]), float(r[2]),
                 float(self._spd_np[0]) * SPEED_NORM_FACTOR)

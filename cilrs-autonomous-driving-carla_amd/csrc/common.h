@@ -168,6 +168,9 @@ int launch_nchw3_to_nhwc4(const float* x, float* out, int N, int H, int W, long 
                           long sh, long sw, hipStream_t s);
 int launch_u8hwc_to_nhwc4(const unsigned char* x, float* out, size_t npix, const float* mean,
                           const float* stdv, hipStream_t s);
+int launch_camera_to_nhwc4(const unsigned char* src, float* out, int B, int sh, int sw,
+                           int pix_stride, long row_stride, long frame_stride, int H, int W,
+                           const float* mean, const float* stdv, hipStream_t s);
 int launch_pad_cin3_to_4(const float* w3, float* w4, int n_taps_total, hipStream_t s);
 int launch_linear_small_fwd(const float* x, const float* w, const float* bias, float* y, int B,
                             int in, int out, int x_ld, int y_ld, int relu, hipStream_t s);
@@ -183,6 +186,30 @@ int launch_sum_parts(const float* p0, const float* p1, const float* p2, const fl
                      const float* p4, float* out, int B, int cols, int cols4, hipStream_t s);
 int launch_dropout(float* a, int B, int cols, int ld, float p, unsigned long long seed,
                    unsigned long long stream, hipStream_t s);
+// small-batch inference heads (eval, B <= kHeadsSmallMaxB): only the commanded branch of each
+// sample is evaluated (the reference evaluates all four and gathers, autonomous_drive.py:394-398;
+// the discarded ones do not influence the result).  Chain 0 = control branches, 1 = speed head.
+constexpr int kHeadsSmallMaxB = 16;
+struct HeadsSmallArgs {
+    const float* x[2];       // input rows per chain, leading dimension x_ld
+    const float* w[5];       // branch 0..3 weights [out][in], then the speed-head layer
+    const float* b[5];
+    float* y[2];
+    int y_ld[2];
+    int out[2];
+    int in[2];               // input features per chain
+    int x_ld, relu, B;
+    const long long* cmd;    // [B] command per row
+    int* status;             // set to 1 on a command outside 0..3 (may be NULL)
+};
+int launch_heads_small_pre(const float* feat, int HW, const float* speed, const float* w0,
+                           const float* b0, const float* w1, const float* b1, float* combined,
+                           int B, hipStream_t s);
+int launch_heads_small_layer(const HeadsSmallArgs& a, hipStream_t s);
+constexpr int kEvalAccDoubles = 72;
+int launch_eval_accumulate(const float* pc, const float* tc, const float* ps, const float* ts,
+                           const long long* cmd, int B, double* acc, float* steer_err,
+                           hipStream_t s);
 int launch_branch_gather(const float* all_out, const long long* cmd, float* controls, int B,
                          int nbranch, int* status, hipStream_t s);
 int launch_branch_scatter(const float* dcontrols, const long long* cmd, float* d_all, int B,

@@ -61,6 +61,58 @@ __global__ __launch_bounds__(256) void u8hwc_to_nhwc4_kernel(const unsigned char
     }
 }
 
+// Camera frames -> network input in one pass: cv2.resize(frame, (W, H)) [bilinear, uint8 result],
+// /255, HWC->CHW, Normalize (autonomous_drive.py:897-902; camera layout :868-872 = 600x800 BGRA
+// with the first three bytes of each pixel kept, in that order).  The bilinear step restates
+// OpenCV's 8-bit INTER_LINEAR: 11-bit fixed-point coefficients rounded to nearest-even,
+// horizontal pass in int, vertical pass ((b*(v>>4))>>16 summed, +2, >>2).
+__device__ __forceinline__ void resize_coef(const int d, const double scale, const int ssize,
+                                            const bool zero_frac_at_edge, int& s0, int& c0,
+                                            int& c1) {
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int si = (int)floorf(f);
+    f -= (float)si;
+    if (zero_frac_at_edge) {          // horizontal: out-of-range taps lose their fraction
+        if (si < 0) { f = 0.f; si = 0; }
+        if (si >= ssize - 1) { f = 0.f; si = ssize - 1; }
+    }
+    s0 = si;
+    c0 = __float2int_rn((1.f - f) * 2048.f);
+    c1 = __float2int_rn(f * 2048.f);
+}
+
+__global__ __launch_bounds__(256) void camera_to_nhwc4_kernel(
+    const unsigned char* __restrict__ src, float* __restrict__ out, const int B, const int sh,
+    const int sw, const int pix_stride, const long row_stride, const long frame_stride,
+    const int H, const int W, const double scale_y, const double scale_x, const float m0,
+    const float m1, const float m2, const float d0, const float d1, const float d2) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * H * W) return;
+    const int dx = i % W, dy = (i / W) % H, b = i / (W * H);
+    int sx, a0, a1, sy, b0, b1;
+    resize_coef(dx, scale_x, sw, true, sx, a0, a1);
+    resize_coef(dy, scale_y, sh, false, sy, b0, b1);
+    const int sx1 = min(sx + 1, sw - 1);
+    const int y0 = min(max(sy, 0), sh - 1), y1 = min(max(sy + 1, 0), sh - 1);
+    const unsigned char* f = src + (size_t)b * frame_stride;
+    const unsigned char* r0 = f + (size_t)y0 * row_stride;
+    const unsigned char* r1 = f + (size_t)y1 * row_stride;
+    const float mean[3] = {m0, m1, m2}, stdv[3] = {d0, d1, d2};
+    f32x4 v;
+    v[3] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int h0 = (int)r0[(size_t)sx * pix_stride + c] * a0 +
+                       (int)r0[(size_t)sx1 * pix_stride + c] * a1;
+        const int h1 = (int)r1[(size_t)sx * pix_stride + c] * a0 +
+                       (int)r1[(size_t)sx1 * pix_stride + c] * a1;
+        int u = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+        u = min(max(u, 0), 255);
+        v[c] = ((float)u / 255.0f - mean[c]) / stdv[c];
+    }
+    *reinterpret_cast<f32x4*>(out + (size_t)i * 4) = v;
+}
+
 // stem weights: OHWI with I = 3 -> I padded to 4
 __global__ void pad_cin3_to_4_kernel(const float* __restrict__ w3, float* __restrict__ w4,
                                      const int n_taps_total) {
@@ -234,6 +286,104 @@ __global__ __launch_bounds__(256) void dropout_kernel(float* __restrict__ a, con
     a[o] = (u >= p) ? a[o] / (1.0f - p) : 0.f;
 }
 
+// ---- small-batch inference heads ---------------------------------------------------------------
+// blockIdx.y == 0: AdaptiveAvgPool2d + Flatten of sample blockIdx.x -> combined[b][0:512]
+// blockIdx.y == 1: speed encoder Linear(1,128)+ReLU, Linear(128,128)+ReLU -> combined[b][512:640]
+// (autonomous_drive.py:366-374, 390-392)
+__global__ __launch_bounds__(256) void heads_small_pre_kernel(
+    const float* __restrict__ feat, const int HW, const float* __restrict__ speed,
+    const float* __restrict__ w0, const float* __restrict__ b0, const float* __restrict__ w1,
+    const float* __restrict__ b1, float* __restrict__ combined) {
+    const int b = blockIdx.x;
+    const int t = threadIdx.x;
+    float* out = combined + (size_t)b * 640;
+    if (blockIdx.y == 0) {
+        if (t >= 128) return;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int p = 0; p < HW; ++p)
+            s += *reinterpret_cast<const f32x4*>(feat + ((size_t)b * HW + p) * 512 + t * 4);
+        *reinterpret_cast<f32x4*>(out + t * 4) = s / (float)HW;
+        return;
+    }
+    __shared__ float s1[128];
+    if (t < 128) s1[t] = fmaxf(fmaf(speed[b], w0[t], 0.f) + b0[t], 0.f);
+    __syncthreads();
+    const int lane = t & 63, wave = t >> 6;
+    const float xa = s1[lane], xb = s1[lane + 64];
+    for (int o = wave * 32; o < wave * 32 + 32; ++o) {
+        const float* wr = w1 + (size_t)o * 128;
+        float v = fmaf(xb, wr[lane + 64], xa * wr[lane]);
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) v += __shfl_xor(v, sft);
+        if (lane == 0) out[512 + o] = fmaxf(v + b1[o], 0.f);
+    }
+}
+
+// One wave per output feature: the weight row stays in registers and is applied to every sample
+// row that selects it (chain 0: rows whose command picks branch k; chain 1: all rows).
+__global__ __launch_bounds__(256) void heads_small_layer_kernel(const HeadsSmallArgs a) {
+    const int lane = threadIdx.x & 63;
+    int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int chain = o >= a.out[0] ? 1 : 0;
+    if (chain) o -= a.out[0];
+    if (o >= a.out[chain]) return;
+    const int in = a.in[chain];
+    const int nq = in >> 2;
+    const float* xbase = a.x[chain];
+    float* ybase = a.y[chain];
+    const int y_ld = a.y_ld[chain];
+    const int nk = chain ? 1 : 4;
+    for (int k = 0; k < nk; ++k) {
+        const int widx = chain ? 4 : k;
+        if (!chain) {
+            bool any = false;
+            for (int b = 0; b < a.B; ++b) {
+                const long long c = a.cmd[b];
+                any |= ((c < 0 || c > 3) ? 0 : (int)c) == k;
+            }
+            if (!any) continue;
+        }
+        const float* wr = a.w[widx] + (size_t)o * in;
+        f32x4 wv[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int q = lane + 64 * j;
+            wv[j] = q < nq ? *reinterpret_cast<const f32x4*>(wr + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const float bias = a.b[widx][o];
+        for (int b = 0; b < a.B; ++b) {
+            if (!chain) {
+                const long long c = a.cmd[b];
+                if (((c < 0 || c > 3) ? 0 : (int)c) != k) continue;
+            }
+            const float* xr = xbase + (size_t)b * a.x_ld;
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int q = lane + 64 * j;
+                if (q < nq) {
+                    const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + q * 4);
+                    acc = fmaf(xv[0], wv[j][0], acc);
+                    acc = fmaf(xv[1], wv[j][1], acc);
+                    acc = fmaf(xv[2], wv[j][2], acc);
+                    acc = fmaf(xv[3], wv[j][3], acc);
+                }
+            }
+#pragma unroll
+            for (int sft = 32; sft > 0; sft >>= 1) acc += __shfl_xor(acc, sft);
+            if (lane == 0) {
+                float v = acc + bias;
+                if (a.relu) v = fmaxf(v, 0.f);
+                ybase[(size_t)b * y_ld + o] = v;
+            }
+        }
+    }
+    if (a.status && !chain && o == 0 && lane == 0) {   // torch.gather would raise
+        for (int b = 0; b < a.B; ++b)
+            if (a.cmd[b] < 0 || a.cmd[b] > 3) *a.status = 1;
+    }
+}
+
 // controls[b][j] = all_out[cmd[b]][b][j]   (torch.stack + gather, autonomous_drive.py:395-398)
 __global__ void branch_gather_kernel(const float* __restrict__ all_out,
                                      const long long* __restrict__ cmd,
@@ -260,6 +410,69 @@ __global__ void branch_scatter_kernel(const float* __restrict__ dcontrols,
     const int b = (i >> 2) % B;
     const int k = (i >> 2) / B;
     d_all[i] = (j < 3 && cmd[b] == k) ? dcontrols[b * 3 + j] : 0.f;
+}
+
+// ---- evaluation-report accumulators (schema: evaluation_report.json:1-73) ----------------------
+// acc[0..31]   channel c (steer, throttle, brake, speed) x {n, Sp, St, Spt, Spp, Stt, S|d|, Sdd}
+// acc[32..67]  command k x {n, S|d_steer|, S|d_throttle|, S|d_brake|, Sp, St, Spt, Spp, Stt (steer)}
+// acc[68..71]  rows with |d_steer| <= 0.01, 0.02, 0.05, 0.1
+// Deterministic: slot j is summed by one wave (lanes stride the rows, shuffle tree) in double.
+__device__ __forceinline__ double eval_term(const int j, const float* __restrict__ pc,
+                                            const float* __restrict__ tc,
+                                            const float* __restrict__ ps,
+                                            const float* __restrict__ ts,
+                                            const long long* __restrict__ cmd, const int b) {
+    if (j < 32) {
+        const int c = j >> 3, q = j & 7;
+        const double p = c < 3 ? (double)pc[b * 3 + c] : (double)ps[b];
+        const double t = c < 3 ? (double)tc[b * 3 + c] : (double)ts[b];
+        const double d = p - t;
+        switch (q) {
+            case 0: return 1.0;
+            case 1: return p;
+            case 2: return t;
+            case 3: return p * t;
+            case 4: return p * p;
+            case 5: return t * t;
+            case 6: return fabs(d);
+            default: return d * d;
+        }
+    }
+    if (j < 68) {
+        const int k = (j - 32) / 9, q = (j - 32) % 9;
+        if (cmd[b] != k) return 0.0;
+        const double p = (double)pc[b * 3], t = (double)tc[b * 3];
+        switch (q) {
+            case 0: return 1.0;
+            case 1: return fabs(p - t);
+            case 2: return fabs((double)pc[b * 3 + 1] - (double)tc[b * 3 + 1]);
+            case 3: return fabs((double)pc[b * 3 + 2] - (double)tc[b * 3 + 2]);
+            case 4: return p;
+            case 5: return t;
+            case 6: return p * t;
+            case 7: return p * p;
+            default: return t * t;
+        }
+    }
+    const double thr[4] = {0.01, 0.02, 0.05, 0.1};
+    return fabs((double)pc[b * 3] - (double)tc[b * 3]) <= thr[j - 68] ? 1.0 : 0.0;
+}
+
+__global__ __launch_bounds__(256) void eval_accumulate_kernel(
+    const float* __restrict__ pc, const float* __restrict__ tc, const float* __restrict__ ps,
+    const float* __restrict__ ts, const long long* __restrict__ cmd, const int B,
+    double* __restrict__ acc, float* __restrict__ steer_err) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int j = wave; j < kEvalAccDoubles; j += 4) {
+        double s = 0.0;
+        for (int b = lane; b < B; b += 64) s += eval_term(j, pc, tc, ps, ts, cmd, b);
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) s += __shfl_xor(s, sft);
+        if (lane == 0) acc[j] += s;
+    }
+    if (steer_err)
+        for (int b = threadIdx.x; b < B; b += 256)
+            steer_err[b] = (float)fabs((double)pc[b * 3] - (double)tc[b * 3]);
 }
 
 // ---- loss forward + gradient, one block --------------------------------------------------------
@@ -413,6 +626,22 @@ int launch_u8hwc_to_nhwc4(const unsigned char* x, float* out, size_t npix, const
     return 0;
 }
 
+int launch_camera_to_nhwc4(const unsigned char* src, float* out, int B, int sh, int sw,
+                           int pix_stride, long row_stride, long frame_stride, int H, int W,
+                           const float* mean, const float* stdv, hipStream_t s) {
+    CILRS_CHECK(sh >= 1 && sw >= 1 && (pix_stride == 3 || pix_stride == 4) &&
+                    row_stride >= (long)sw * pix_stride && frame_stride >= (long)sh * row_stride,
+                "camera frame: bad geometry / strides");
+    // cv::resize: scale = 1 / (dsize / ssize), in double
+    const double scale_x = 1.0 / ((double)W / (double)sw);
+    const double scale_y = 1.0 / ((double)H / (double)sh);
+    camera_to_nhwc4_kernel<<<cdiv(B * H * W, 256), 256, 0, s>>>(
+        src, out, B, sh, sw, pix_stride, row_stride, frame_stride, H, W, scale_y, scale_x, mean[0],
+        mean[1], mean[2], stdv[0], stdv[1], stdv[2]);
+    CILRS_LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_pad_cin3_to_4(const float* w3, float* w4, int n_taps_total, hipStream_t s) {
     pad_cin3_to_4_kernel<<<cdiv(n_taps_total, 256), 256, 0, s>>>(w3, w4, n_taps_total);
     CILRS_LAUNCH_CHECK();
@@ -470,6 +699,31 @@ int launch_dropout(float* a, int B, int cols, int ld, float p, unsigned long lon
                    unsigned long long stream, hipStream_t s) {
     CILRS_CHECK(p >= 0.f && p < 1.f, "dropout: p=%f out of range", (double)p);
     dropout_kernel<<<cdiv(B * cols, 256), 256, 0, s>>>(a, B, cols, ld, p, seed, stream);
+    CILRS_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_heads_small_pre(const float* feat, int HW, const float* speed, const float* w0,
+                           const float* b0, const float* w1, const float* b1, float* combined,
+                           int B, hipStream_t s) {
+    heads_small_pre_kernel<<<dim3(B, 2), 256, 0, s>>>(feat, HW, speed, w0, b0, w1, b1, combined);
+    CILRS_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_heads_small_layer(const HeadsSmallArgs& a, hipStream_t s) {
+    CILRS_CHECK(a.B >= 1 && a.B <= kHeadsSmallMaxB, "heads_small: batch out of range");
+    CILRS_CHECK(a.in[0] % 4 == 0 && a.in[0] <= 768 && a.in[1] % 4 == 0 && a.in[1] <= 768 &&
+                    a.x_ld % 4 == 0, "heads_small: bad width");
+    heads_small_layer_kernel<<<cdiv(a.out[0] + a.out[1], 4), 256, 0, s>>>(a);
+    CILRS_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_eval_accumulate(const float* pc, const float* tc, const float* ps, const float* ts,
+                           const long long* cmd, int B, double* acc, float* steer_err,
+                           hipStream_t s) {
+    eval_accumulate_kernel<<<1, 256, 0, s>>>(pc, tc, ps, ts, cmd, B, acc, steer_err);
     CILRS_LAUNCH_CHECK();
     return 0;
 }

@@ -795,6 +795,46 @@ static int forward_from_x4(cilrs_net* net, const cilrs_buffers* bufs, const floa
         }
     }
 
+    int* status = reinterpret_cast<int*>(reinterpret_cast<char*>(bufs->workspace) + net->status_b);
+    if (!train && B <= kHeadsSmallMaxB) {
+        // ---- inference at control-loop batch sizes: 4 launches, commanded branch only ----
+        RUN(net, "heads_fwd", 0.0, 0.0, s,
+            launch_heads_small_pre(cur, net->featHW, speed, P + A.se0.w, P + A.se0.b, P + A.se3.w,
+                                   P + A.se3.b, ws + net->combined, B, s));
+        HeadsSmallArgs h;
+        memset(&h, 0, sizeof(h));
+        h.B = B;
+        h.cmd = reinterpret_cast<const long long*>(command);
+        for (int layer = 0; layer < 3; ++layer) {
+            for (int k = 0; k < 4; ++k) {
+                h.w[k] = P + A.br[k][layer].w;
+                h.b[k] = P + A.br[k][layer].b;
+            }
+            const LinT& sp = layer == 0 ? A.sp0 : layer == 1 ? A.sp3 : A.sp5;
+            h.w[4] = P + sp.w;
+            h.b[4] = P + sp.b;
+            h.in[0] = A.br[0][layer].in;
+            h.in[1] = sp.in;
+            h.x_ld = h.in[0];
+            h.x[0] = layer == 0 ? ws + net->combined : layer == 1 ? ws + net->h1[0] : ws + net->h2[0];
+            h.x[1] = layer == 0 ? ws + net->combined : layer == 1 ? ws + net->p1 : ws + net->p2;
+            h.y[0] = layer == 0 ? ws + net->h1[0] : layer == 1 ? ws + net->h2[0] : controls;
+            h.y[1] = layer == 0 ? ws + net->p1 : layer == 1 ? ws + net->p2 : pred_speed;
+            h.out[0] = A.br[0][layer].out;
+            h.out[1] = sp.out;
+            h.y_ld[0] = h.out[0];
+            h.y_ld[1] = h.out[1];
+            h.relu = layer < 2;
+            h.status = layer == 2 ? status : nullptr;
+            RUN(net, "heads_fwd", 2.0 * B * (h.in[0] * h.out[0] + h.in[1] * h.out[1]),
+                4.0 * (h.in[0] * h.out[0] + h.in[1] * h.out[1]), s,
+                launch_heads_small_layer(h, s));
+        }
+        net->trained_fwd = false;
+        net->last_dropout = 0.f;
+        return 0;
+    }
+
     // ---- avgpool + flatten -> combined[:, 0:512] ----
     RUN(net, "heads_fwd", 0.0, 0.0, s,
         launch_avgpool_fwd(cur, ws + net->combined, B, net->featHW, 512, 640, s));
@@ -846,7 +886,6 @@ static int forward_from_x4(cilrs_net* net, const cilrs_buffers* bufs, const floa
     }
     if (join_streams(net, s, 5)) return 1;
     // gathered by command (:397-398)
-    int* status = reinterpret_cast<int*>(reinterpret_cast<char*>(bufs->workspace) + net->status_b);
     RUN(net, "heads_fwd", 0.0, 0.0, s,
         launch_branch_gather(ws + net->all_out, reinterpret_cast<const long long*>(command),
                              controls, B, 4, status, s));
@@ -892,6 +931,23 @@ int cilrs_net_forward_u8(cilrs_net* net, const cilrs_buffers* bufs, const uint8_
     RUN(net, "transform", 0.0, 0.0, s,
         launch_u8hwc_to_nhwc4(frames, ws + net->x4, (size_t)net->B * net->H * net->W, mean, stdv,
                               s));
+    return forward_from_x4(net, bufs, speed, command, 0, 0.f, 0, controls, pred_speed, s);
+}
+
+int cilrs_net_forward_camera(cilrs_net* net, const cilrs_buffers* bufs, const uint8_t* frames,
+                             int src_h, int src_w, int pixel_stride, long row_stride,
+                             long frame_stride, const float* speed, const int64_t* command,
+                             float* controls, float* pred_speed, void* stream) {
+    if (check_bufs(net, bufs, false)) return 1;
+    CILRS_CHECK(frames && speed && command && controls && pred_speed,
+                "forward_camera: NULL tensor");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    float* ws = reinterpret_cast<float*>(bufs->workspace);
+    CILRS_HIP(hipMemsetAsync(reinterpret_cast<char*>(bufs->workspace) + net->status_b, 0, 16, s));
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    RUN(net, "transform", 0.0, 0.0, s,
+        launch_camera_to_nhwc4(frames, ws + net->x4, net->B, src_h, src_w, pixel_stride,
+                               row_stride, frame_stride, net->H, net->W, mean, stdv, s));
     return forward_from_x4(net, bufs, speed, command, 0, 0.f, 0, controls, pred_speed, s);
 }
 
@@ -1174,6 +1230,20 @@ int cilrs_adam_step(float* params, const float* grads, float* exp_avg, float* ex
 int cilrs_scale(float* x, size_t n, const float* clip_out2, float c, void* stream) {
     CILRS_CHECK(x != nullptr, "scale: NULL argument");
     return launch_scale(x, n, clip_out2, c, reinterpret_cast<hipStream_t>(stream));
+}
+
+int cilrs_eval_acc_doubles(void) { return kEvalAccDoubles; }
+
+int cilrs_eval_accumulate(const float* controls, const float* pred_speed,
+                          const float* target_controls, const float* target_speed,
+                          const int64_t* command, int batch, double* acc, float* steer_abs_err,
+                          void* stream) {
+    CILRS_CHECK(controls && pred_speed && target_controls && target_speed && command && acc,
+                "eval_accumulate: NULL argument");
+    CILRS_CHECK(batch >= 1, "eval_accumulate: empty batch");
+    return launch_eval_accumulate(controls, target_controls, pred_speed, target_speed,
+                                  reinterpret_cast<const long long*>(command), batch, acc,
+                                  steer_abs_err, reinterpret_cast<hipStream_t>(stream));
 }
 
 int cilrs_net_profile_enable(cilrs_net* net, int on) {

@@ -79,6 +79,17 @@ int cilrs_net_forward_u8(cilrs_net* net, const cilrs_buffers* bufs, const uint8_
                          const float* speed, const int64_t* command, float* controls,
                          float* pred_speed, void* stream);
 
+/* Same, fed with raw camera frames of any size: fuses preprocess_image completely --
+ * cv2.resize(frame, (W, H)) (8-bit INTER_LINEAR, restated; cv2 is absent from the build image so
+ * this step is parity-unpinned), /255, HWC->CHW, Normalize (autonomous_drive.py:897-902).
+ * frames: [B] images of src_h x src_w pixels, pixel_stride 3 or 4 bytes (the CARLA camera hands
+ * over 600x800 BGRA and the agent keeps bytes 0..2 of each pixel, :868-872), row_stride and
+ * frame_stride in bytes. */
+int cilrs_net_forward_camera(cilrs_net* net, const cilrs_buffers* bufs, const uint8_t* frames,
+                             int src_h, int src_w, int pixel_stride, long row_stride,
+                             long frame_stride, const float* speed, const int64_t* command,
+                             float* controls, float* pred_speed, void* stream);
+
 /* cilrs_net_forward_u8 replayed from a cached hipGraph (re-captured when a pointer changes);
  * `stream` must be a non-default stream.  Single-frame control loop: predict_controls,
  * autonomous_drive.py:908-920. */
@@ -122,6 +133,20 @@ int cilrs_adam_step(float* params, const float* grads, float* exp_avg, float* ex
                     double weight_decay, int64_t step, const float* clip_out2, float grad_scale,
                     void* stream);
 int cilrs_scale(float* x, size_t n, const float* clip_out2, float c, void* stream);
+
+/* ---- evaluation report accumulators (metrics schema evaluation_report.json:1-73; the reference
+ *      ships the report, not the code that made it) ---------------------------------------------
+ * acc: cilrs_eval_acc_doubles() doubles on the device, zeroed by the caller before the first
+ * batch and ADDED to by every call:
+ *   [0..31]  channel c in (steer, throttle, brake, speed) x {n, Sp, St, Spt, Spp, Stt, S|d|, Sdd}
+ *   [32..67] command k x {n, S|d_steer|, S|d_throttle|, S|d_brake|, then steer Sp, St, Spt, Spp, Stt}
+ *   [68..71] rows with |d_steer| <= 0.01, 0.02, 0.05, 0.1
+ * steer_abs_err (may be NULL): [batch] floats, |steer error| per row (for the percentiles). */
+int cilrs_eval_acc_doubles(void);
+int cilrs_eval_accumulate(const float* controls, const float* pred_speed,
+                          const float* target_controls, const float* target_speed,
+                          const int64_t* command, int batch, double* acc, float* steer_abs_err,
+                          void* stream);
 
 /* ---- per-kernel timing (hipEvents on the launch stream; feeds bench.py's roofline) ---------- */
 int cilrs_net_profile_enable(cilrs_net* net, int on);

@@ -268,6 +268,50 @@ def preprocess_frame(rgb_u8_hwc: np.ndarray) -> torch.Tensor:
     return ((img - mean) / std).unsqueeze(0)
 
 
+def resize_bilinear_u8(frame: np.ndarray, width: int = IMG_W, height: int = IMG_H) -> np.ndarray:
+    """cv2.resize(frame, (width, height)) for uint8 HWC frames with the default INTER_LINEAR
+    (autonomous_drive.py:898).  cv2 is not installed in the build image, so this restates
+    OpenCV's published 8-bit algorithm -- PARITY UNPINNED against cv2 itself:
+      coefficient f = float((d + 0.5) * scale - 0.5), s = floor(f), f -= s; horizontally a tap
+      left of 0 / right of the last column drops its fraction; weights round(f * 2048) and
+      round((1 - f) * 2048) (nearest-even) as int16; horizontal pass in int32; vertical pass
+      ((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2 with rows clipped."""
+    assert frame.dtype == np.uint8 and frame.ndim == 3
+    sh, sw = frame.shape[:2]
+    if (sh, sw) == (height, width):
+        return frame.copy()
+
+    def coefs(dsize, ssize, zero_edge):
+        scale = 1.0 / (np.float64(dsize) / np.float64(ssize))
+        f = ((np.arange(dsize, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+        s0 = np.floor(f).astype(np.int64)
+        f = f - s0.astype(np.float32)
+        if zero_edge:
+            lo, hi = s0 < 0, s0 >= ssize - 1
+            f = np.where(lo | hi, np.float32(0), f)
+            s0 = np.where(lo, 0, np.where(hi, ssize - 1, s0))
+        c0 = np.rint((np.float32(1) - f) * np.float32(2048)).astype(np.int64)
+        c1 = np.rint(f * np.float32(2048)).astype(np.int64)
+        return s0, c0, c1
+
+    sx, a0, a1 = coefs(width, sw, True)
+    sy, b0, b1 = coefs(height, sh, False)
+    sx1 = np.minimum(sx + 1, sw - 1)
+    y0 = np.clip(sy, 0, sh - 1)
+    y1 = np.clip(sy + 1, 0, sh - 1)
+    src = frame.astype(np.int64)
+    hrow = src[:, sx, :] * a0[None, :, None] + src[:, sx1, :] * a1[None, :, None]   # [sh, W, C]
+    h0, h1 = hrow[y0], hrow[y1]
+    out = (((b0[:, None, None] * (h0 >> 4)) >> 16) + ((b1[:, None, None] * (h1 >> 4)) >> 16) + 2) >> 2
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def preprocess_camera(frame_u8: np.ndarray) -> torch.Tensor:
+    """Whole preprocess_image (:897-902): camera frame (any size, 3 or 4 bytes per pixel, first
+    three kept like :870) -> f32 [1,3,88,200]."""
+    return preprocess_frame(resize_bilinear_u8(np.ascontiguousarray(frame_u8[:, :, :3])))
+
+
 @torch.no_grad()
 def predict_controls(model, rgb_u8_hwc, speed_kmh, command_idx):
     """(:908-920) -> (steer, throttle, brake, speed_kmh)."""

@@ -98,6 +98,25 @@ def same(a, b):
     return a.shape == b.shape and bool((a == b).all())
 
 
+def camera_fixture(orc):
+    """Whole preprocess_image incl. the resize (autonomous_drive.py:868-872, 897-902): a 600x800
+    4-byte-per-pixel camera frame -> resized bytes (digest + samples) -> controls.  cv2 is absent,
+    so the resize is the oracle's restatement of OpenCV's 8-bit INTER_LINEAR (parity unpinned)."""
+    import hashlib
+    cam = np.floor(O._hash_u01(4321, 9, 600 * 800 * 4) * 256).astype(np.uint8).reshape(600, 800, 4)
+    small = O.resize_bilinear_u8(np.ascontiguousarray(cam[:, :, :3]))
+    with torch.no_grad():
+        x = O.preprocess_camera(cam)
+        pc, ps = orc.eval()(x, torch.tensor([min(40.0 / 90.0, 1.0)]), torch.tensor([2]))
+    json.dump(dict(frame_seed=4321, frame_stream=9, shape=[600, 800, 4],
+                   resized_sha256=hashlib.sha256(small.tobytes()).hexdigest(),
+                   resized_sum=int(small.astype(np.int64).sum()),
+                   resized_row0=small[0, :8].reshape(-1).tolist(),
+                   speed_kmh=40.0, command=2,
+                   out=[pc[0, 0].item(), pc[0, 1].item(), pc[0, 2].item(), ps[0].item() * 90.0]),
+              open(os.path.join(OUT, "camera_pipeline.json"), "w"))
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -231,6 +250,7 @@ def main():
         cases[0]["out"]
     json.dump(dict(frame_seed=1234, frame_stream=7, frame_sum=int(frame.astype(np.int64).sum()),
                    cases=cases), open(os.path.join(OUT, "infer_pipeline.json"), "w"))
+    camera_fixture(orc)
     print("golden fixtures written to", OUT)
     for f in sorted(os.listdir(OUT)):
         print(f"  {f}: {os.path.getsize(os.path.join(OUT, f))} B")

@@ -216,3 +216,68 @@ def test_dp_equivalence_semantics_with_oracle():
     loss.backward()
     diff = max(float((p.grad - a).abs().max()) for p, a in zip(m.parameters(), avg))
     assert diff > 1e-4          # batch statistics differ: DP is NOT one big batch
+
+
+def test_evaluation_report_oracle_schema_and_identities(golden_dir):
+    """The reference ships evaluation_report.json but not its generator: pin the oracle's report
+    on the published key structure and on the identities the published numbers satisfy."""
+    import eval_report as ER
+    g = json.load(open(os.path.join(golden_dir, "evaluation_report_schema.json")))
+    for name, (mse, rmse) in g["mse_rmse"].items():          # published: RMSE == sqrt(MSE)
+        assert abs(rmse - mse ** 0.5) <= 1e-12, name
+    assert sum(g["per_command_n"].values()) == g["val_samples"]
+    rng = np.random.default_rng(5)
+    n = 500
+    tc = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+    ts = rng.uniform(0, 1, n).astype(np.float32)
+    pc = (tc + rng.normal(0, 0.03, (n, 3))).astype(np.float32)
+    ps = (ts + rng.normal(0, 0.02, n)).astype(np.float32)
+    cmd = rng.integers(0, 4, n)
+    rep = ER.evaluation_report(pc, ps, tc, ts, cmd, checkpoint_epoch=3)
+
+    def keys(d):
+        return {k: (keys(v) if isinstance(v, dict) else type(v).__name__) for k, v in d.items()}
+    assert keys(rep) == g["schema"]
+    # known answers: numpy's own estimators
+    assert abs(rep["overall_metrics"]["Steer"]["Correlation"]
+               - np.corrcoef(pc[:, 0].astype(np.float64), tc[:, 0].astype(np.float64))[0, 1]) < 1e-12
+    assert abs(rep["overall_metrics"]["Speed"]["RMSE"] ** 2 - rep["overall_metrics"]["Speed"]["MSE"]) < 1e-15
+    assert sum(v["n"] for v in rep["per_command_metrics"].values()) == rep["val_samples"] == n
+    b = rep["steer_accuracy_buckets"]
+    assert b["within_0.01"] <= b["within_0.02"] <= b["within_0.05"] <= b["within_0.1"] <= 1.0
+    p = rep["steer_percentiles"]
+    assert p["P50"] <= p["P75"] <= p["P90"] <= p["P95"] <= p["P99"]
+    # weighted per-command steer MAE reassembles the overall one
+    tot = sum(v["n"] * v["steer_mae"] for v in rep["per_command_metrics"].values()) / n
+    assert abs(tot - rep["overall_metrics"]["Steer"]["MAE"]) < 1e-14
+
+
+def test_oracle_resize_restatement(golden_dir):
+    """OpenCV 8-bit INTER_LINEAR restated (cv2 absent -> parity unpinned): golden digest, and the
+    properties the algorithm guarantees -- identity at equal size, constants preserved, within one
+    grey level of exact bilinear sampling, channel order untouched."""
+    import hashlib
+    g = json.load(open(os.path.join(golden_dir, "camera_pipeline.json")))
+    cam = np.floor(O._hash_u01(g["frame_seed"], g["frame_stream"], 600 * 800 * 4) * 256)
+    cam = cam.astype(np.uint8).reshape(600, 800, 4)
+    rgb = np.ascontiguousarray(cam[:, :, :3])
+    small = O.resize_bilinear_u8(rgb)
+    assert small.shape == (88, 200, 3) and small.dtype == np.uint8
+    assert hashlib.sha256(small.tobytes()).hexdigest() == g["resized_sha256"]
+    assert small[0, :8].reshape(-1).tolist() == g["resized_row0"]
+    same = O.resize_bilinear_u8(small)
+    assert same is not small and np.array_equal(same, small)
+    assert np.unique(O.resize_bilinear_u8(np.full((600, 800, 3), 201, np.uint8))).tolist() == [201]
+    fx = (np.arange(200) + 0.5) * 4 - 0.5
+    fy = (np.arange(88) + 0.5) * (600 / 88) - 0.5
+    x0, y0 = np.floor(fx).astype(int), np.floor(fy).astype(int)
+    wx, wy = (fx - x0)[None, :, None], (fy - y0)[:, None, None]
+    F = rgb.astype(np.float64)
+    top = F[y0][:, x0] * (1 - wx) + F[y0][:, x0 + 1] * wx
+    bot = F[y0 + 1][:, x0] * (1 - wx) + F[y0 + 1][:, x0 + 1] * wx
+    assert np.abs(small - (top * (1 - wy) + bot * wy)).max() <= 1.0
+    for c in range(3):
+        assert np.array_equal(O.resize_bilinear_u8(rgb[:, :, c:c + 1])[:, :, 0], small[:, :, c])
+    # upscaling exercises the clamped edge taps
+    up = O.resize_bilinear_u8(small[:10, :12], width=31, height=23)
+    assert up.shape == (23, 31, 3) and up.min() >= small[:10, :12].min()

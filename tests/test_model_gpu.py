@@ -350,6 +350,23 @@ def test_batched_eval_matches_oracle():
     assert (s.cpu() - os_).abs().max() <= TOL_OUT
 
 
+@pytest.mark.parametrize("B", [16, 17])
+def test_small_batch_heads_match_full_heads(B):
+    """B <= 16 eval takes the commanded-branch-only heads (4 launches), B >= 17 the all-branch
+    matrix path (autonomous_drive.py:394-398); both must agree with the oracle on every command,
+    with one command absent from the batch."""
+    m = make_model().eval()
+    orc = O.build_oracle(0).eval()
+    img, spd, _, _, _ = O.synthetic_batch(B, seed=17)
+    cmd = torch.tensor([(3 * i) % 4 if (3 * i) % 4 != 2 else 0 for i in range(B)])
+    assert 2 not in cmd.tolist() and {0, 1, 3} <= set(cmd.tolist())
+    with torch.no_grad():
+        oc, os_ = orc(img, spd, cmd)
+        c, s = m(*to_dev(img, spd, cmd))
+    assert (c.cpu() - oc).abs().max() <= TOL_OUT
+    assert (s.cpu() - os_).abs().max() <= TOL_OUT
+
+
 @pytest.mark.parametrize("B,H,W", [(3, 96, 160), (2, 90, 202), (1, 88, 200), (5, 64, 64)])
 def test_other_geometries_forward_and_step(B, H, W):
     """The plan is geometry-generic (odd pooling edges, tiny feature maps, B=1 batch statistics):
@@ -389,3 +406,97 @@ def test_predictor_graph_replay_matches_eager():
     graph = Predictor(m, use_graph=True)
     b = [graph.predict_controls(frame, 30.0 + i, i % 4) for i in range(4)]
     assert a == b
+
+
+def test_eval_accumulate_kernel_matches_oracle():
+    """cilrs_eval_accumulate + Evaluator.report vs the numpy restatement on the same predictions
+    (three ragged batches, one command absent, rows exactly on a bucket threshold)."""
+    import eval_report as ER
+    from cilrs_mi355.evaluate import Evaluator
+    rng = np.random.default_rng(11)
+    n = 128 + 77 + 1
+    tc = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+    ts = rng.uniform(0, 1, n).astype(np.float32)
+    pc = (tc + rng.normal(0, 0.03, (n, 3))).astype(np.float32)
+    ps = (ts + rng.normal(0, 0.02, n)).astype(np.float32)
+    pc[5, 0], tc[5, 0] = np.float32(0.5), np.float32(0.25)
+    cmd = rng.integers(0, 3, n)                     # command 3 never occurs
+    ev = Evaluator(make_model().eval(), capacity=100)          # forces the error log to grow
+    dev = ev.device
+    lo = 0
+    for b in (128, 77, 1):
+        sl = slice(lo, lo + b)
+        ev.update_predictions(torch.from_numpy(pc[sl]).to(dev), torch.from_numpy(ps[sl]).to(dev),
+                              torch.from_numpy(tc[sl]).to(dev), torch.from_numpy(ts[sl]).to(dev),
+                              torch.from_numpy(cmd[sl]).to(dev))
+        lo += b
+    rep = ev.report(checkpoint_epoch=7)
+    ref = ER.evaluation_report(pc, ps, tc, ts, cmd, checkpoint_epoch=7)
+
+    def cmp(a, b, path=""):
+        assert type(a) is type(b), path
+        if isinstance(a, dict):
+            assert a.keys() == b.keys(), path
+            for k in a:
+                cmp(a[k], b[k], path + "/" + k)
+        elif isinstance(a, float):
+            assert abs(a - b) <= 1e-10 * max(1.0, abs(b)), (path, a, b)
+        else:
+            assert a == b, (path, a, b)
+    cmp(rep, ref)
+    assert "STRAIGHT" not in rep["per_command_metrics"]
+    assert rep["steer_accuracy_buckets"] == ref["steer_accuracy_buckets"]      # counts are exact
+
+
+def test_evaluate_end_to_end_vs_oracle_model():
+    """evaluate(): eval forwards through the HIP plan + device accumulation, against the report
+    the oracle model's own CPU predictions give (tolerance = forward tolerance)."""
+    import eval_report as ER
+    from cilrs_mi355.evaluate import evaluate
+    m = make_model().train()                         # evaluate() must switch to eval and back
+    orc = O.build_oracle(0).eval()
+    batches, P, S, T, TS, Cm = [], [], [], [], [], []
+    for i, b in enumerate((8, 5)):
+        img, spd, cmd, tgt, _ = O.synthetic_batch(b, seed=40 + i)
+        with torch.no_grad():
+            oc, os_ = orc(img, spd, cmd)
+        P.append(oc.numpy()); S.append(os_.numpy()); T.append(tgt.numpy())
+        TS.append(spd.numpy()); Cm.append(cmd.numpy())
+        batches.append(to_dev(img, spd, cmd, tgt))
+    rep = evaluate(m, batches, checkpoint_epoch=1)
+    assert m.training
+    ref = ER.evaluation_report(np.concatenate(P), np.concatenate(S), np.concatenate(T),
+                               np.concatenate(TS), np.concatenate(Cm), checkpoint_epoch=1)
+    assert rep["val_samples"] == 13
+    for ch in ref["overall_metrics"]:
+        for k, v in ref["overall_metrics"][ch].items():
+            assert abs(rep["overall_metrics"][ch][k] - v) <= 2e-4, (ch, k)
+    for c, d in ref["per_command_metrics"].items():
+        assert rep["per_command_metrics"][c]["n"] == d["n"]
+        assert abs(rep["per_command_metrics"][c]["steer_mae"] - d["steer_mae"]) <= TOL_OUT
+    for q, v in ref["steer_percentiles"].items():
+        assert abs(rep["steer_percentiles"][q] - v) <= TOL_OUT
+
+
+def test_camera_path_fused_resize(golden_dir):
+    """predict_controls on a raw 600x800x4 camera frame (resize fused into the HIP transform,
+    autonomous_drive.py:868-872, 897-902): bit-identical to feeding the oracle-resized 88x200
+    frame through the uint8 path (so the device resize == the restated cv2 algorithm on every
+    pixel), and within 1e-4 of the golden / oracle outputs."""
+    from cilrs_mi355.predict import Predictor
+    g = json.load(open(os.path.join(golden_dir, "camera_pipeline.json")))
+    cam = np.floor(O._hash_u01(g["frame_seed"], g["frame_stream"], 600 * 800 * 4) * 256)
+    cam = cam.astype(np.uint8).reshape(600, 800, 4)
+    pr = Predictor(make_model())
+    got = pr.predict_controls(cam, g["speed_kmh"], g["command"])
+    small = O.resize_bilinear_u8(np.ascontiguousarray(cam[:, :, :3]))
+    via_u8 = pr.predict_controls(small, g["speed_kmh"], g["command"])
+    assert got == via_u8
+    for i, (a, b) in enumerate(zip(got, g["out"])):
+        assert abs(a - b) <= (TOL_OUT if i < 3 else TOL_OUT * 90.0)      # speed is scaled by 90
+    # 3-byte pixels, another size (up- and down-scaling mixed: 50x300 -> 88x200)
+    odd = np.floor(O._hash_u01(7, 3, 50 * 300 * 3) * 256).astype(np.uint8).reshape(50, 300, 3)
+    assert pr.predict_controls(odd, 10.0, 1) == \
+        pr.predict_controls(O.resize_bilinear_u8(odd), 10.0, 1)
+    with pytest.raises(RuntimeError):
+        pr.predict_controls(np.zeros((600, 800), np.uint8), 10.0, 1)
