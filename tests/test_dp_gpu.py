@@ -1,0 +1,101 @@
+"""Data-parallel train step with two real ranks on one MI355X.
+
+RCCL refuses two ranks on the same device, so the two processes talk through gloo (device tensors
+staged by the backend); everything else -- the HIP plan, the bucketed all-reduce issued between
+backward segments, the 1/world gradient scale folded into Adam -- is the production path that
+`bench.py --gpus N` runs over RCCL.  Expected values: the oracle's per-shard gradients (per-replica
+BatchNorm statistics) averaged, then one Adam step.
+"""
+import os
+
+import pytest
+import torch
+
+import cilrs_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, q, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from cilrs_mi355 import CILRS, CONFIG_A, Trainer
+        from cilrs_mi355.parallel import broadcast_parameters
+        torch.cuda.set_device(0)
+        m = CILRS(4, dropout=0.0)
+        # rank 1 starts from different weights: the broadcast must overwrite them
+        m.load_state_dict(O.portable_state_dict(m.state_dict(), 0 if rank == 0 else 5), strict=True)
+        m = m.cuda()
+        tr = Trainer(m, CONFIG_A, process_group=dist.group.WORLD)
+        broadcast_parameters(tr.eng, dist.group.WORLD)
+        losses = []
+        for step in range(2):
+            imgs, spds, cmds, tgts = O.synthetic_batch(4, seed=60 + 10 * step + rank)[:4]
+            tr.train_step(imgs.cuda(), spds.cuda(), cmds.cuda(), tgts.cuda())
+            losses.append(tr.losses()["total"])
+        torch.cuda.synchronize()
+        path = os.path.join(out_dir, f"rank{rank}.pt")
+        torch.save({k: v.detach().cpu() for k, v in m.state_dict().items()}, path)
+        q.put((rank, None, losses, path))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:                                   # surface the failure in the parent
+        import traceback
+        q.put((rank, traceback.format_exc() + str(e), None, None))
+
+
+def test_two_rank_train_step_matches_oracle_dp_semantics(tmp_path):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(120)
+    for r in res:
+        assert r[1] is None, r[1]
+    sd0, sd1 = (torch.load(res[r][3], weights_only=True) for r in range(2))
+    # replicas stay bit-identical in their parameters; BN buffers are per-replica
+    for k in sd0:
+        if "running_" in k or "num_batches" in k:
+            continue
+        assert torch.equal(sd0[k], sd1[k]), k
+    assert not torch.equal(sd0["visual_encoder.1.running_mean"], sd1["visual_encoder.1.running_mean"])
+
+    # oracle: per-shard gradients averaged, one Adam step -- twice
+    lr = O.CONFIG_A.lr
+    reps = [O.build_oracle(0) for _ in range(2)]             # per-rank BN buffers
+    opt = O.make_optimizer(reps[0], O.CONFIG_A)
+    for step in range(2):
+        grads, want_losses = [], []
+        for rank in range(2):
+            m = reps[rank].train()
+            m.zero_grad()
+            imgs, spds, cmds, tgts = O.synthetic_batch(4, seed=60 + 10 * step + rank)[:4]
+            pc, ps = m(imgs, spds, cmds)
+            loss, _ = O.compute_loss(O.CONFIG_A, pc, tgts, ps, spds)
+            loss.backward()
+            want_losses.append(float(loss.detach()))
+            grads.append([p.grad.clone() for p in m.parameters()])
+        for p, a, b in zip(reps[0].parameters(), *grads):
+            p.grad = (a + b) / 2
+        opt.step()
+        with torch.no_grad():
+            for p0, p1 in zip(reps[0].parameters(), reps[1].parameters()):
+                p1.copy_(p0)
+        tol = 1e-4 if step == 0 else 1e-3
+        for rank in range(2):
+            assert abs(res[rank][2][step] - want_losses[rank]) <= tol * max(1.0, want_losses[rank])
+    for (n, p) in reps[0].named_parameters():
+        err = (sd0[n] - p.detach()).abs()
+        assert float(err.max()) <= 2.2 * lr * 2 + 1e-6, n       # Adam's lr*sign(g) ambiguity
+        assert int((err > 2e-5).sum()) <= max(4, int(0.6 * err.numel())), n
+    # rank 1's BN statistics followed ITS shard
+    want_rm1 = reps[1].state_dict()["visual_encoder.1.running_mean"]
+    assert (sd1["visual_encoder.1.running_mean"] - want_rm1).abs().max() <= 1e-5
