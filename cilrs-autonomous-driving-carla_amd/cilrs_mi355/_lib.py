@@ -55,6 +55,7 @@ SIGNATURES = {
     "cilrs_grad_sqnorm": (i32, [vp, sz, f32, vp, vp, vp]),
     "cilrs_adam_step": (i32, [vp, vp, vp, vp, sz, f64, f64, f64, f64, f64, i64, vp, f32, vp]),
     "cilrs_scale": (i32, [vp, sz, vp, f32, vp]),
+    "cilrs_augment_u8": (i32, [vp, vp, i32, i32, i32, vp, vp, vp]),
     "cilrs_eval_acc_doubles": (i32, []),
     "cilrs_eval_accumulate": (i32, [vp, vp, vp, vp, vp, i32, vp, vp, vp]),
     "cilrs_net_profile_enable": (i32, [vp, i32]),

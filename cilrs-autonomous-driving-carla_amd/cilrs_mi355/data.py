@@ -1,0 +1,253 @@
+"""Input pipeline for real driving data (reference notebook/notebook.ipynb:353-431,
+on-disk format model/collect_data.py:545-564, 683-716, model/prepare_dataset.py:47-61).
+
+On disk:  <data_dir>/sessionN/measurements.csv  (14 columns; this loader uses image_filename, steer,
+throttle, brake, speed_normalized, command_name) and  <data_dir>/sessionN/images/frame_%08d.jpg
+(200x88 JPEG).  The reference decodes and augments each frame on two CPU DataLoader workers; here
+the host only parses the CSVs, draws the class-balanced sample indices and each sample's random
+augmentation parameters, and decodes JPEGs on a thread pool into a pinned uint8 batch -- the
+augmentation itself, /255 and Normalize run as one HIP kernel (`cilrs_augment_u8`).
+"""
+from __future__ import annotations
+
+import csv
+import ctypes as C
+import os
+import queue
+import threading
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+COMMAND_MAP = {"LANEFOLLOW": 0, "LEFT": 1, "RIGHT": 2, "STRAIGHT": 3}     # notebook.ipynb:358
+IMG_HEIGHT, IMG_WIDTH = 88, 200
+
+# numpy mirror of `cilrs_aug_params` (include/cilrs_hip.h), 112 bytes
+AUG_DTYPE = np.dtype([
+    ("noise_seed", np.uint64), ("rbc_on", np.int32), ("alpha", np.float32),
+    ("beta255", np.float32), ("hsv_on", np.int32), ("hue", np.float32), ("sat", np.float32),
+    ("val", np.float32), ("blur_k", np.int32), ("blur_w", np.float32, 3),
+    ("noise_std255", np.float32), ("nholes", np.int32), ("hole_y0", np.int32, 3),
+    ("hole_x0", np.int32, 3), ("hole_y1", np.int32, 3), ("hole_x1", np.int32, 3),
+    ("reserved", np.int32)], align=True)
+assert AUG_DTYPE.itemsize == 112
+
+
+def identity_params(batch: int) -> np.ndarray:
+    """Every augmentation off (validation: only /255 + Normalize)."""
+    p = np.zeros(batch, dtype=AUG_DTYPE)
+    p["alpha"] = 1.0
+    return p
+
+
+def gaussian_taps(ksize: int, sigma: float) -> np.ndarray:
+    """cv2.getGaussianKernel(ksize, sigma) as (centre, +-1, +-2) float32 weights."""
+    r = ksize // 2
+    x = np.arange(-r, r + 1, dtype=np.float64)
+    w = np.exp(-(x * x) / (2.0 * sigma * sigma))
+    w /= w.sum()
+    out = np.zeros(3, dtype=np.float32)
+    out[:r + 1] = w[r:].astype(np.float32)
+    return out
+
+
+def draw_aug_params(rng: np.random.Generator, batch: int, height: int = IMG_HEIGHT,
+                    width: int = IMG_WIDTH) -> np.ndarray:
+    """Per-sample parameters of the reference's train_augmentation (notebook.ipynb:387-394):
+    RandomBrightnessContrast(0.2, 0.2, p=.5), HueSaturationValue(10, 20, 15, p=.3),
+    GaussianBlur(blur_limit=(3,5), p=.2), GaussNoise(std_range=(.02,.06), p=.3),
+    CoarseDropout(1-3 holes, h 4-10, w 8-20, fill 0, p=.2)."""
+    p = identity_params(batch)
+    for i in range(batch):
+        if rng.random() < 0.5:
+            p["rbc_on"][i] = 1
+            p["alpha"][i] = 1.0 + rng.uniform(-0.2, 0.2)
+            p["beta255"][i] = rng.uniform(-0.2, 0.2) * 255.0
+        if rng.random() < 0.3:
+            p["hsv_on"][i] = 1
+            p["hue"][i] = rng.uniform(-10, 10)
+            p["sat"][i] = rng.uniform(-20, 20)
+            p["val"][i] = rng.uniform(-15, 15)
+        if rng.random() < 0.2:
+            k = int(rng.choice((3, 5)))
+            p["blur_k"][i] = k
+            p["blur_w"][i] = gaussian_taps(k, rng.uniform(0.5, 3.0))
+        if rng.random() < 0.3:
+            p["noise_std255"][i] = rng.uniform(0.02, 0.06) * 255.0
+            p["noise_seed"][i] = rng.integers(0, 1 << 63, dtype=np.uint64)
+        if rng.random() < 0.2:
+            n = int(rng.integers(1, 4))
+            p["nholes"][i] = n
+            for k in range(n):
+                hh, ww = int(rng.integers(4, 11)), int(rng.integers(8, 21))
+                y0, x0 = int(rng.integers(0, height - hh + 1)), int(rng.integers(0, width - ww + 1))
+                p["hole_y0"][i, k], p["hole_x0"][i, k] = y0, x0
+                p["hole_y1"][i, k], p["hole_x1"][i, k] = y0 + hh, x0 + ww
+    return p
+
+
+def check_params(p: np.ndarray, height: int, width: int):
+    if p.dtype != AUG_DTYPE:
+        raise RuntimeError("augmentation parameters must use data.AUG_DTYPE")
+    if not np.isin(p["blur_k"], (0, 1, 3, 5)).all():
+        raise RuntimeError("blur_k must be 0, 1, 3 or 5")
+    if (p["nholes"] < 0).any() or (p["nholes"] > 3).any():
+        raise RuntimeError("nholes must be 0..3")
+    if (p["hole_y1"] > height).any() or (p["hole_x1"] > width).any() or \
+            (p["hole_y0"] < 0).any() or (p["hole_x0"] < 0).any():
+        raise RuntimeError("dropout hole outside the frame")
+
+
+def augment_u8(frames_u8: torch.Tensor, params: np.ndarray, want_u8: bool = False):
+    """frames uint8 [B,H,W,3] on the device + per-sample parameters -> normalised image as the
+    logical NCHW float tensor `CILRS.forward` takes (a permuted view of the NHWC result, like the
+    reference's permute at notebook.ipynb:413) [, augmented uint8 frames]."""
+    if frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4 or frames_u8.size(3) != 3 \
+            or frames_u8.device.type != "cuda":
+        raise RuntimeError("augment_u8: frames must be uint8 [B,H,W,3] on the GPU (no CPU fallback)")
+    b, h, w = frames_u8.size(0), frames_u8.size(1), frames_u8.size(2)
+    if params.shape != (b,):
+        raise RuntimeError("augment_u8: one parameter record per frame")
+    check_params(params, h, w)
+    frames_u8 = frames_u8.contiguous()
+    pdev = torch.from_numpy(params.view(np.uint8).reshape(b, AUG_DTYPE.itemsize)).to(
+        frames_u8.device, non_blocking=False)
+    out = torch.empty(b, h, w, 3, dtype=torch.float32, device=frames_u8.device)
+    out8 = torch.empty_like(frames_u8) if want_u8 else None
+    stream = torch.cuda.current_stream(frames_u8.device).cuda_stream
+    L.check(L.lib().cilrs_augment_u8(L.ptr(frames_u8), L.ptr(pdev), b, h, w, L.ptr(out),
+                                     L.ptr(out8), C.c_void_p(stream)))
+    img = out.permute(0, 3, 1, 2)
+    return (img, out8) if want_u8 else img
+
+
+# ---- dataset on disk -------------------------------------------------------------------------
+class Sessions:
+    """All `sessionN/measurements.csv` under data_dir, concatenated (notebook.ipynb:360-372)."""
+
+    def __init__(self, data_dir: str):
+        names = sorted(d for d in os.listdir(data_dir)
+                       if os.path.isdir(os.path.join(data_dir, d)) and "session" in d)
+        if not names:
+            raise RuntimeError(f"no session directories under {data_dir}")
+        paths, cols = [], {k: [] for k in ("steer", "throttle", "brake", "speed_normalized")}
+        cmds = []
+        for s in names:
+            with open(os.path.join(data_dir, s, "measurements.csv"), newline="") as f:
+                for row in csv.DictReader(f):
+                    paths.append(os.path.join(data_dir, s, "images", row["image_filename"]))
+                    for k in cols:
+                        cols[k].append(float(row[k]))
+                    if row["command_name"] not in COMMAND_MAP:
+                        raise RuntimeError(f"unknown command_name {row['command_name']!r} in {s}")
+                    cmds.append(COMMAND_MAP[row["command_name"]])
+        self.paths = np.array(paths, dtype=object)
+        self.targets = np.stack([np.array(cols[k], dtype=np.float32)
+                                 for k in ("steer", "throttle", "brake")], axis=1)
+        self.speed = np.array(cols["speed_normalized"], dtype=np.float32)
+        self.command = np.array(cmds, dtype=np.int64)
+
+    def __len__(self):
+        return len(self.paths)
+
+    def split(self, test_size=0.15, random_state=42):
+        """The reference's stratified split (notebook.ipynb:376-377) -> (train_idx, val_idx)."""
+        from sklearn.model_selection import train_test_split
+        idx = np.arange(len(self))
+        tr, va = train_test_split(idx, test_size=test_size, random_state=random_state,
+                                  stratify=self.command)
+        return tr, va
+
+
+def class_balanced_weights(command: np.ndarray) -> np.ndarray:
+    """Per-sample weight len / (4 * count[command]) (notebook.ipynb:383-384, 421)."""
+    counts = np.bincount(command, minlength=4).astype(np.float64)
+    cw = len(command) / (4.0 * np.where(counts > 0, counts, 1.0))
+    return cw[command]
+
+
+def weighted_indices(weights: np.ndarray, num_samples: int, generator=None) -> torch.Tensor:
+    """WeightedRandomSampler(weights, num_samples, replacement=True) (notebook.ipynb:422-423):
+    torch.multinomial over the double weights."""
+    return torch.multinomial(torch.as_tensor(weights, dtype=torch.double), num_samples, True,
+                             generator=generator)
+
+
+def decode_jpeg(path: str) -> np.ndarray:
+    """cv2.imread + BGR2RGB (notebook.ipynb:408-409) -> uint8 RGB [H,W,3]."""
+    from PIL import Image
+    with Image.open(path) as im:
+        return np.asarray(im.convert("RGB"), dtype=np.uint8)
+
+
+class BatchLoader:
+    """Iterates (image, speed, command, targets) device batches like the reference's DataLoader
+    (notebook.ipynb:428-431).  train=True: class-balanced sampling with replacement, device-side
+    augmentation, drop_last; train=False: sequential, no augmentation, last partial batch kept.
+    JPEGs are decoded by `workers` threads into pinned memory one batch ahead of the consumer."""
+
+    def __init__(self, sessions: Sessions, indices, batch_size: int, device, train: bool,
+                 seed: int = 0, workers: int = 8, height: int = IMG_HEIGHT, width: int = IMG_WIDTH):
+        self.s, self.idx = sessions, np.asarray(indices)
+        self.bs, self.device, self.train = batch_size, torch.device(device), train
+        self.h, self.w = height, width
+        self.rng = np.random.default_rng(seed)
+        self.gen = torch.Generator().manual_seed(seed)
+        self.pool = ThreadPoolExecutor(max_workers=max(1, workers))
+        self.weights = class_balanced_weights(sessions.command[self.idx]) if train else None
+
+    def __len__(self):
+        n = len(self.idx)
+        return n // self.bs if self.train else (n + self.bs - 1) // self.bs
+
+    def _order(self):
+        if self.train:
+            pick = weighted_indices(self.weights, len(self.idx), self.gen).numpy()
+            return self.idx[pick]
+        return self.idx
+
+    def _stage(self, ids):
+        """decode one batch into a fresh pinned buffer (worker threads; PIL releases the GIL)"""
+        host = torch.empty(len(ids), self.h, self.w, 3, dtype=torch.uint8).pin_memory()
+        view = host.numpy()
+
+        def one(k):
+            img = decode_jpeg(self.s.paths[ids[k]])
+            if img.shape != (self.h, self.w, 3):
+                raise RuntimeError(f"{self.s.paths[ids[k]]}: expected {self.w}x{self.h} RGB, got "
+                                   f"{img.shape}")
+            view[k] = img
+        list(self.pool.map(one, range(len(ids))))
+        params = draw_aug_params(self.rng, len(ids), self.h, self.w) if self.train \
+            else identity_params(len(ids))
+        return host, params, ids
+
+    def __iter__(self):
+        order = self._order()
+        nb = len(self)
+        q: queue.Queue = queue.Queue(maxsize=2)
+
+        def producer():
+            try:
+                for b in range(nb):
+                    q.put(self._stage(order[b * self.bs:(b + 1) * self.bs]))
+                q.put(None)
+            except Exception as e:          # surface decode errors in the consumer
+                q.put(e)
+        threading.Thread(target=producer, daemon=True).start()
+        while True:
+            item = q.get()
+            if item is None:
+                return
+            if isinstance(item, Exception):
+                raise item
+            host, params, ids = item
+            frames = host.to(self.device, non_blocking=True)
+            img = augment_u8(frames, params)
+            yield (img,
+                   torch.from_numpy(self.s.speed[ids]).to(self.device, non_blocking=True),
+                   torch.from_numpy(self.s.command[ids]).to(self.device, non_blocking=True),
+                   torch.from_numpy(self.s.targets[ids]).to(self.device, non_blocking=True))

@@ -18,7 +18,7 @@ namespace {
 
 constexpr int kMaxPartBlocks = 1024;
 
-// partial[blk][0][c] = sum_rows v1, partial[blk][1][c] = sum_rows v2
+// partial[0][c][blk] = sum_rows v1, partial[1][c][blk] = sum_rows v2   (channel-major)
 // MODE 0: v1 = y, v2 = y*y                     (forward statistics)
 // MODE 1: v1 = g, v2 = g * (y - mean) * rstd   (backward reductions), g = dz * (z > 0 if relu)
 template <int MODE>
@@ -88,49 +88,47 @@ __global__ __launch_bounds__(256) void bn_colreduce_kernel(
             a1 += red[0][(rs * tpr + qq) * 4 + e];
             a2 += red[1][(rs * tpr + qq) * 4 + e];
         }
-        partial[(size_t)blockIdx.x * 2 * C + c] = a1;
-        partial[(size_t)blockIdx.x * 2 * C + C + c] = a2;
+        partial[(size_t)c * gridDim.x + blockIdx.x] = a1;
+        partial[(size_t)(C + c) * gridDim.x + blockIdx.x] = a2;
     }
 }
 
-// Sum the per-block partials of 32 channels: 8 thread groups stride over the blocks in double,
-// then a fixed-order LDS combine (deterministic).  Returns the two sums to threads g == 0.
+// Sum one channel's per-block partials (channel-major layout [2][C][nblk]): one wave per channel,
+// lanes stride the blocks in double over four independent streams, fixed-order shuffle tree
+// (deterministic).  Returns the two sums to lane 0 of the wave.
+constexpr int kFinChannels = 4;       // channels (waves) per finalize block
 __device__ __forceinline__ bool partial_sums(const float* __restrict__ partial, const int nblk,
                                              const int C, int& c, double& s1, double& s2) {
-    __shared__ double red[2][32][32];
-    const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
-    const int ng = blockDim.x >> 5;           // 8 or 32 partial-groups
-    c = blockIdx.x * 32 + cl;
-    double a1 = 0.0, a2 = 0.0;
-    if (c < C) {
-        // four independent load streams per thread (fixed order => deterministic)
-        double p1[4] = {0.0, 0.0, 0.0, 0.0}, p2[4] = {0.0, 0.0, 0.0, 0.0};
-        int b = g;
-        for (; b + 3 * ng < nblk; b += 4 * ng) {
+    const int lane = threadIdx.x & 63;
+    c = blockIdx.x * kFinChannels + (threadIdx.x >> 6);
+    if (c >= C) return false;
+    const float* r1 = partial + (size_t)c * nblk;
+    const float* r2 = partial + (size_t)(C + c) * nblk;
+    double p1[4] = {0.0, 0.0, 0.0, 0.0}, p2[4] = {0.0, 0.0, 0.0, 0.0};
+    int b = lane;
+    for (; b + 192 < nblk; b += 256) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                p1[u] += (double)partial[(size_t)(b + u * ng) * 2 * C + c];
-                p2[u] += (double)partial[(size_t)(b + u * ng) * 2 * C + C + c];
-            }
+        for (int u = 0; u < 4; ++u) {
+            p1[u] += (double)r1[b + 64 * u];
+            p2[u] += (double)r2[b + 64 * u];
         }
-        for (; b < nblk; b += ng) {
-            p1[0] += (double)partial[(size_t)b * 2 * C + c];
-            p2[0] += (double)partial[(size_t)b * 2 * C + C + c];
-        }
-        a1 = (p1[0] + p1[1]) + (p1[2] + p1[3]);
-        a2 = (p2[0] + p2[1]) + (p2[2] + p2[3]);
     }
-    red[0][g][cl] = a1;
-    red[1][g][cl] = a2;
-    __syncthreads();
-    if (g != 0 || c >= C) return false;
-    s1 = 0.0; s2 = 0.0;
-    for (int k = 0; k < ng; ++k) { s1 += red[0][k][cl]; s2 += red[1][k][cl]; }
-    return true;
+    for (; b < nblk; b += 64) {
+        p1[0] += (double)r1[b];
+        p2[0] += (double)r2[b];
+    }
+    s1 = (p1[0] + p1[1]) + (p1[2] + p1[3]);
+    s2 = (p2[0] + p2[1]) + (p2[2] + p2[3]);
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) {
+        s1 += __shfl_xor(s1, sft);
+        s2 += __shfl_xor(s2, sft);
+    }
+    return lane == 0;
 }
 
 // stats layout (floats): [0,C) mean | [C,2C) rstd | [2C,3C) w = gamma*rstd | [3C,4C) b = beta-mean*w
-__global__ __launch_bounds__(1024) void bn_fwd_finalize_kernel(
+__global__ __launch_bounds__(64 * kFinChannels) void bn_fwd_finalize_kernel(
     const float* __restrict__ partial, const int nblk, const int M, const int C,
     const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
     float* running_var, long long* nbt, const float momentum, const float eps,
@@ -218,7 +216,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 }
 
 // coef layout: [0,C) c1 = gamma*rstd | [C,2C) c2 = sum(g)/M | [2C,3C) c3 = sum(g*xhat)/M
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(
+__global__ __launch_bounds__(64 * kFinChannels) void bn_bwd_finalize_kernel(
     const float* __restrict__ partial, const int nblk, const int M, const int C,
     const float* __restrict__ gamma, const float* __restrict__ stats, float* dgamma,
     float* dbeta, float* __restrict__ coef, const int accumulate) {
@@ -423,7 +421,7 @@ int launch_bn_train_fwd(const float* y, int M, int C, const float* gamma, const 
         CILRS_LAUNCH_CHECK();
         nblk = p.nblk;
     }
-    bn_fwd_finalize_kernel<<<cdiv(C, 32), 1024, 0, s>>>(partial, nblk, M, C, gamma, beta,
+    bn_fwd_finalize_kernel<<<cdiv(C, kFinChannels), 64 * kFinChannels, 0, s>>>(partial, nblk, M, C, gamma, beta,
                                                         running_mean, running_var, nbt, momentum,
                                                         eps, stats);
     CILRS_LAUNCH_CHECK();
@@ -468,7 +466,7 @@ int launch_bn_bwd(const float* dz, const float* z, const float* y, int M, int C,
         CILRS_LAUNCH_CHECK();
         nblk = p.nblk;
     }
-    bn_bwd_finalize_kernel<<<cdiv(C, 32), 1024, 0, s>>>(partial, nblk, M, C, gamma, stats,
+    bn_bwd_finalize_kernel<<<cdiv(C, kFinChannels), 64 * kFinChannels, 0, s>>>(partial, nblk, M, C, gamma, stats,
                                                         dgamma, dbeta, coef, accumulate);
     CILRS_LAUNCH_CHECK();
     const size_t total4 = (size_t)M * C / 4;

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include "../../include/cilrs_hip.h"
 
 namespace cilrs {
 
@@ -206,6 +207,8 @@ int launch_heads_small_pre(const float* feat, int HW, const float* speed, const 
                            const float* b0, const float* w1, const float* b1, float* combined,
                            int B, hipStream_t s);
 int launch_heads_small_layer(const HeadsSmallArgs& a, hipStream_t s);
+int launch_augment_u8(const unsigned char* frames, const cilrs_aug_params* params, int B, int H,
+                      int W, float* out_f32, unsigned char* out_u8, hipStream_t s);
 constexpr int kEvalAccDoubles = 72;
 int launch_eval_accumulate(const float* pc, const float* tc, const float* ps, const float* ts,
                            const long long* cmd, int B, double* acc, float* steer_err,

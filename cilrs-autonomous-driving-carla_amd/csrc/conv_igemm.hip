@@ -389,9 +389,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a, co
                 t1 += red[(w * BN + tid) * 2];
                 t2 += red[(w * BN + tid) * 2 + 1];
             }
-            const size_t mt = (size_t)(logical / tilesN);
-            a.bn_partial[mt * 2 * a.Cout + n0 + tid] = t1;
-            a.bn_partial[mt * 2 * a.Cout + a.Cout + n0 + tid] = t2;
+            // channel-major partials [2][Cout][M-tiles]: the finalize reads each channel's row
+            const size_t mt = (size_t)(logical / tilesN), nmt = (size_t)((M + BM - 1) / BM);
+            a.bn_partial[(size_t)(n0 + tid) * nmt + mt] = t1;
+            a.bn_partial[(size_t)(a.Cout + n0 + tid) * nmt + mt] = t2;
         }
     }
 
@@ -507,9 +508,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a, co
                 t1 += red[(w * BN + tid) * 2];
                 t2 += red[(w * BN + tid) * 2 + 1];
             }
-            const size_t mt = (size_t)(logical / tilesN);
-            a.bwd_partial[mt * 2 * a.Cout + n0 + tid] = t1;
-            a.bwd_partial[mt * 2 * a.Cout + a.Cout + n0 + tid] = t2;
+            const size_t mt = (size_t)(logical / tilesN), nmt = (size_t)((M + BM - 1) / BM);
+            a.bwd_partial[(size_t)(n0 + tid) * nmt + mt] = t1;
+            a.bwd_partial[(size_t)(a.Cout + n0 + tid) * nmt + mt] = t2;
         }
     }
 }

@@ -210,6 +210,19 @@ using namespace cilrs;
 struct ConvG { int H, W, Ho, Wo, M; size_t y, z, stats; };
 constexpr int kTileCounters = 16384, kHeadCounters = 1024;
 
+// dy ring: bn_bwd writes each conv's output gradient into the next ring slot; the weight-gradient
+// GEMM that consumes it runs on side stream 0 and may lag the data-gradient chain by up to
+// depth - 1 convolutions.  Measured on MI355X (tools/overlap_sweep.sh): depth 2/4/8 all give
+// 14.58-14.65 ms/step, and a LOW-PRIORITY side stream (CILRS_SIDE_PRIO=1) starves the weight
+// gradients outright (25.3 ms/step) -- so the defaults are depth 2, default priority.
+constexpr int kDyRing = 8;
+constexpr int kNumG = 5 + kDyRing - 2;
+constexpr int kRingIdx[kDyRing] = {0, 4, 5, 6, 7, 8, 9, 10};
+static int dy_ring_depth() {
+    static const int d = getenv("CILRS_DY_RING") ? atoi(getenv("CILRS_DY_RING")) : 2;
+    return d < 2 ? 2 : d > kDyRing ? kDyRing : d;
+}
+
 struct cilrs_net {
     int B, H, W;
     std::vector<ConvG> cg;                 // geometry + workspace offsets (floats) per conv
@@ -222,7 +235,7 @@ struct cilrs_net {
     size_t hscr[5], hscr_floats, hslab[5], hslab_floats;   // per-chain scratch of the heads
     size_t tile_cnt, hcnt[5];              // split-K ticket counters (ints; trunk / head chains)
     const void* cnt_zeroed_for = nullptr;  // workspace whose counters have been zeroed
-    size_t G[5];                           // rotating gradient buffers (max activation size)
+    size_t G[kNumG];                       // gradient buffers: [1..3] fixed roles, the rest = dy ring
     size_t gmax;
     size_t bn_partial, bn_coef, slabs, slabs_floats, ksplit, ksplit_floats, status_b;
     size_t ws_bytes;
@@ -232,9 +245,9 @@ struct cilrs_net {
     bool overlap = true;
     bool streams_ready = false;
     hipStream_t side[5];
-    hipEvent_t fork_ev, join_ev[5], gbuf_ev[5];
-    bool gbuf_pending[5] = {false, false, false, false, false};
-    int dy_toggle = 0;
+    hipEvent_t fork_ev, join_ev[5], gbuf_ev[kNumG];
+    bool gbuf_pending[kNumG] = {};
+    int dy_pos = 0;
     int bwd_nblk_next = 0;                 // fused BN-backward partials waiting for their BN
     BnEvalTable bn_table;
     // cached hipGraph of the uint8 inference path (fixed pointers)
@@ -291,11 +304,20 @@ int zero_counters_once(cilrs_net* net, void* workspace, hipStream_t s) {
 
 int ensure_streams(cilrs_net* net) {
     if (net->streams_ready) return 0;
+    int prio_least = 0, prio_greatest = 0;
+    CILRS_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    // side stream 0 carries the weight-gradient GEMMs (CILRS_SIDE_PRIO=1: lowest priority -- an
+    // experiment that starves them, see kDyRing)
+    static const int side_prio = getenv("CILRS_SIDE_PRIO") ? atoi(getenv("CILRS_SIDE_PRIO")) : 0;
     for (int i = 0; i < 5; ++i) {
-        CILRS_HIP(hipStreamCreateWithFlags(&net->side[i], hipStreamNonBlocking));
+        if (i == 0 && side_prio)
+            CILRS_HIP(hipStreamCreateWithPriority(&net->side[i], hipStreamNonBlocking, prio_least));
+        else
+            CILRS_HIP(hipStreamCreateWithFlags(&net->side[i], hipStreamNonBlocking));
         CILRS_HIP(hipEventCreateWithFlags(&net->join_ev[i], hipEventDisableTiming));
-        CILRS_HIP(hipEventCreateWithFlags(&net->gbuf_ev[i], hipEventDisableTiming));
     }
+    for (int i = 0; i < kNumG; ++i)
+        CILRS_HIP(hipEventCreateWithFlags(&net->gbuf_ev[i], hipEventDisableTiming));
     CILRS_HIP(hipEventCreateWithFlags(&net->fork_ev, hipEventDisableTiming));
     net->streams_ready = true;
     return 0;
@@ -349,7 +371,7 @@ int gbuf_side_end(cilrs_net* net, int gi) {
     return 0;
 }
 int gbuf_join_all(cilrs_net* net, hipStream_t main) {
-    for (int gi = 0; gi < 5; ++gi)
+    for (int gi = 0; gi < kNumG; ++gi)
         if (gbuf_acquire(net, main, gi)) return 1;
     return 0;
 }
@@ -559,6 +581,7 @@ int cilrs_net_create(int batch, int height, int width, cilrs_net** out) {
         n->H1 = out_dim(g.Ho, 3, 2, 1); n->W1 = out_dim(g.Wo, 3, 2, 1);
     }
     size_t gmax = (size_t)n->cg[0].M * 64;
+    size_t dymax = 0;
     n->pool = bump.take((size_t)B * n->H1 * n->W1 * 64);
     const size_t argmax_floats = ((size_t)B * n->H1 * n->W1 * 64 + 3) / 4;
     n->argmax_b = bump.take(argmax_floats) * sizeof(float);
@@ -606,6 +629,7 @@ int cilrs_net_create(int batch, int height, int width, cilrs_net** out) {
         const size_t act = (size_t)B * h * w * c1.cin;
         if (act > gmax) gmax = act;
         if ((size_t)g1.M * c1.cout > gmax) gmax = (size_t)g1.M * c1.cout;
+        if ((size_t)g1.M * c1.cout > dymax) dymax = (size_t)g1.M * c1.cout;   // trunk dy tensors
         h = g1.Ho; w = g1.Wo;
     }
     n->featHW = h * w;
@@ -648,6 +672,7 @@ int cilrs_net_create(int batch, int height, int width, cilrs_net** out) {
     }
     n->gmax = gmax;
     for (int i = 0; i < 5; ++i) n->G[i] = bump.take(gmax);
+    for (int i = 5; i < kNumG; ++i) n->G[i] = bump.take(dymax);
     {
         size_t need = bn_partial_floats(512);
         for (size_t ci = 0; ci < A.convs.size(); ++ci) {
@@ -682,8 +707,8 @@ void cilrs_net_destroy(cilrs_net* net) {
         for (int i = 0; i < 5; ++i) {
             (void)hipStreamDestroy(net->side[i]);
             (void)hipEventDestroy(net->join_ev[i]);
-            (void)hipEventDestroy(net->gbuf_ev[i]);
         }
+        for (int i = 0; i < kNumG; ++i) (void)hipEventDestroy(net->gbuf_ev[i]);
         (void)hipEventDestroy(net->fork_ev);
     }
     if (net && net->graph_exec) (void)hipGraphExecDestroy(net->graph_exec);
@@ -1054,8 +1079,8 @@ int cilrs_net_backward(cilrs_net* net, const cilrs_buffers* bufs, const float* d
                     return gbuf_side_end(net, gi);
                 };
                 // 1. out = relu(bn2(y2) + identity): masked grad -> Gb, dy2 -> Ga
-                int ga = net->dy_toggle ? 4 : 0;
-                net->dy_toggle ^= 1;
+                int ga = kRingIdx[net->dy_pos];
+                net->dy_pos = (net->dy_pos + 1) % dy_ring_depth();
                 if (gbuf_acquire(net, s, ga) || gbuf_acquire(net, s, 1)) return 1;
                 float* Ga = ws + net->G[ga];
                 RUN(net, "bn_bwd." + grp, 0.0, 4.0 * g2.M * c2.cout * 8.0, s,
@@ -1071,8 +1096,8 @@ int cilrs_net_backward(cilrs_net* net, const cilrs_buffers* bufs, const float* d
                 if (conv_dgrad(net, c2, g2, Ga, P + c2.w, Gc, nullptr, ws, s, &g1, 1, &nb1))
                     return 1;
                 // 4. a = relu(bn1(y1)): dy1 -> the other dy buffer
-                ga = net->dy_toggle ? 4 : 0;
-                net->dy_toggle ^= 1;
+                ga = kRingIdx[net->dy_pos];
+                net->dy_pos = (net->dy_pos + 1) % dy_ring_depth();
                 if (gbuf_acquire(net, s, ga)) return 1;
                 Ga = ws + net->G[ga];
                 RUN(net, "bn_bwd." + grp, 0.0, 4.0 * g1.M * c1.cout * 7.0, s,
@@ -1093,14 +1118,17 @@ int cilrs_net_backward(cilrs_net* net, const cilrs_buffers* bufs, const float* d
                     const BnT& bd = A.bns[cd.bn];
                     if (conv_dgrad(net, c1, g1, Ga, P + c1.w, Gd, nullptr, ws, s)) return 1;
                     // 7. identity = bn_d(conv_d(x)) (no ReLU): dy_d -> Gc
-                    if (gbuf_acquire(net, s, 2)) return 1;
+                    const int gdn = kRingIdx[net->dy_pos];
+                    net->dy_pos = (net->dy_pos + 1) % dy_ring_depth();
+                    if (gbuf_acquire(net, s, gdn)) return 1;
+                    float* Gdn = ws + net->G[gdn];
                     RUN(net, "bn_bwd." + grp, 0.0, 4.0 * gd.M * cd.cout * 6.0, s,
                         launch_bn_bwd(Gb, nullptr, ws + gd.y, gd.M, cd.cout, P + bd.gamma,
                                       ws + gd.stats, 0, Gp + bd.gamma, Gp + bd.beta, 0,
-                                      ws + net->bn_coef, ws + net->bn_partial, Gc, nullptr, 0, s));
-                    if (wgrad_side(cd, gd, xin, 2, Gp + cd.w)) return 1;
+                                      ws + net->bn_coef, ws + net->bn_partial, Gdn, nullptr, 0, s));
+                    if (wgrad_side(cd, gd, xin, gdn, Gp + cd.w)) return 1;
                     // 8. dx += dgrad(conv_d)
-                    if (conv_dgrad(net, cd, gd, Gc, P + cd.w, Gd, Gd, ws, s)) return 1;
+                    if (conv_dgrad(net, cd, gd, Gdn, P + cd.w, Gd, Gd, ws, s)) return 1;
                 }
             }
             // the segment's weight gradients are complete when this call returns its work
@@ -1230,6 +1258,14 @@ int cilrs_adam_step(float* params, const float* grads, float* exp_avg, float* ex
 int cilrs_scale(float* x, size_t n, const float* clip_out2, float c, void* stream) {
     CILRS_CHECK(x != nullptr, "scale: NULL argument");
     return launch_scale(x, n, clip_out2, c, reinterpret_cast<hipStream_t>(stream));
+}
+
+int cilrs_augment_u8(const uint8_t* frames, const cilrs_aug_params* params, int batch, int height,
+                     int width, float* out_f32, uint8_t* out_u8, void* stream) {
+    CILRS_CHECK(frames && params && (out_f32 || out_u8), "augment: NULL argument");
+    static_assert(sizeof(cilrs_aug_params) == 112, "cilrs_aug_params layout");
+    return launch_augment_u8(frames, params, batch, height, width, out_f32, out_u8,
+                             reinterpret_cast<hipStream_t>(stream));
 }
 
 int cilrs_eval_acc_doubles(void) { return kEvalAccDoubles; }

@@ -134,6 +134,33 @@ int cilrs_adam_step(float* params, const float* grads, float* exp_avg, float* ex
                     void* stream);
 int cilrs_scale(float* x, size_t n, const float* clip_out2, float c, void* stream);
 
+/* ---- training input pipeline on the device ------------------------------------
+ * The reference's per-frame CPU augmentation (albumentations Compose, notebook/notebook.ipynb:387-394:
+ * RandomBrightnessContrast p.5, HueSaturationValue p.3, GaussianBlur p.2, GaussNoise p.3,
+ * CoarseDropout p.2) + /255 + Normalize (:412-414) as one kernel over a uint8 batch.  The random
+ * parameters of each sample are drawn by the caller; a step is disabled by its *_on / 0 value.
+ * albumentations / cv2 are absent from the build image: the steps restate their published
+ * behaviour and are parity-unpinned against the libraries themselves. */
+typedef struct {
+    uint64_t noise_seed;     /* counter-based RNG key of this sample's Gaussian noise            */
+    int rbc_on;              /* v' = trunc(clip(v * alpha + beta255))                             */
+    float alpha, beta255;
+    int hsv_on;              /* 8-bit HSV (H in half-degrees): H+hue mod 180, S+sat, V+val clipped */
+    float hue, sat, val;
+    int blur_k;              /* 0/1 = off, 3 or 5 = Gaussian taps; blur_w = centre, +-1, +-2      */
+    float blur_w[3];
+    float noise_std255;      /* 0 = off; sigma in grey levels                                      */
+    int nholes;              /* 0..3 rectangles [y0,y1) x [x0,x1) set to 0                         */
+    int hole_y0[3], hole_x0[3], hole_y1[3], hole_x1[3];
+    int reserved;
+} cilrs_aug_params;          /* 112 bytes */
+
+/* frames uint8 [B,H,W,3] (device), params [B] (device) -> out_f32 [B,H,W,3] normalised floats
+ * (feed it to cilrs_net_forward as the NCHW view with strides (H*W*3, 1, W*3, 3)) and/or out_u8
+ * [B,H,W,3] augmented bytes; either output may be NULL. */
+int cilrs_augment_u8(const uint8_t* frames, const cilrs_aug_params* params, int batch, int height,
+                     int width, float* out_f32, uint8_t* out_u8, void* stream);
+
 /* ---- evaluation report accumulators (metrics schema evaluation_report.json:1-73; the reference
  *      ships the report, not the code that made it) ---------------------------------------------
  * acc: cilrs_eval_acc_doubles() doubles on the device, zeroed by the caller before the first

@@ -281,3 +281,103 @@ def test_oracle_resize_restatement(golden_dir):
     # upscaling exercises the clamped edge taps
     up = O.resize_bilinear_u8(small[:10, :12], width=31, height=23)
     assert up.shape == (23, 31, 3) and up.min() >= small[:10, :12].min()
+
+
+# ---- input pipeline: host side ------------------------------------------------
+CSV_COLUMNS = ["frame", "image_filename", "steer", "throttle", "brake", "speed_kmh",
+               "speed_normalized", "high_level_command", "command_name", "position_x",
+               "position_y", "position_z", "yaw", "timestamp"]          # collect_data.py:549-564
+
+
+def make_sessions(root, n_per_session=(7, 5), seed=3):
+    """A dataset in the reference's on-disk format (collect_data.py:545-564, 683-716)."""
+    import csv
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    names = ["LANEFOLLOW", "LEFT", "RIGHT", "STRAIGHT"]
+    frames = []
+    for si, n in enumerate(n_per_session):
+        sdir = os.path.join(root, f"session{si + 1}")
+        os.makedirs(os.path.join(sdir, "images"))
+        with open(os.path.join(sdir, "measurements.csv"), "w", newline="") as f:
+            wr = csv.writer(f)
+            wr.writerow(CSV_COLUMNS)
+            for k in range(n):
+                # smooth images so JPEG round trips stay close
+                base = rng.integers(0, 256, (11, 25, 3), dtype=np.uint8)
+                img = np.asarray(Image.fromarray(base).resize((200, 88), Image.BILINEAR))
+                fn = f"frame_{k:08d}.jpg"
+                Image.fromarray(img).save(os.path.join(sdir, "images", fn), quality=95)
+                c = int(rng.integers(0, 4)) if k >= 4 else k
+                kmh = float(rng.uniform(0, 90))
+                wr.writerow([k, fn, round(float(rng.uniform(-1, 1)), 6),
+                             round(float(rng.uniform(0, 1)), 6), round(float(rng.uniform(0, 1)), 6),
+                             round(kmh, 2), round(kmh / 90.0, 6), c, names[c], 1.0, 2.0, 0.5, 90.0,
+                             round(0.05 * k, 3)])
+                frames.append(img)
+    return frames
+
+
+def test_sessions_reader_sampler_and_split(tmp_path):
+    from cilrs_mi355 import data as D
+    make_sessions(str(tmp_path), (12, 9))
+    s = D.Sessions(str(tmp_path))
+    assert len(s) == 21 and s.targets.shape == (21, 3) and s.command.dtype == np.int64
+    assert s.paths[0].endswith(os.path.join("session1", "images", "frame_00000000.jpg"))
+    assert set(s.command[:4].tolist()) == {0, 1, 2, 3}
+    img = D.decode_jpeg(s.paths[0])
+    assert img.shape == (88, 200, 3) and img.dtype == np.uint8
+    # class weights: len / (4 * count)  (notebook.ipynb:384)
+    w = D.class_balanced_weights(s.command)
+    cnt = np.bincount(s.command, minlength=4)
+    assert np.allclose(w, 21 / (4 * cnt[s.command]))
+    # identical draws to the reference's WeightedRandomSampler (notebook.ipynb:422-423)
+    from torch.utils.data import WeightedRandomSampler
+    ref = list(WeightedRandomSampler(torch.DoubleTensor(w), num_samples=21, replacement=True,
+                                     generator=torch.Generator().manual_seed(9)))
+    got = D.weighted_indices(w, 21, torch.Generator().manual_seed(9)).tolist()
+    assert got == ref
+    tr, va = s.split()
+    assert len(va) == 4 and len(tr) == 17 and not set(tr) & set(va)
+    assert D.AUG_DTYPE.itemsize == 112          # cilrs_aug_params, include/cilrs_hip.h
+    with pytest.raises(RuntimeError):
+        D.augment_u8(torch.zeros(1, 88, 200, 3, dtype=torch.uint8), D.identity_params(1))
+
+
+def test_augment_oracle_properties():
+    import augment_oracle as AO
+    from cilrs_mi355 import data as D
+    rng = np.random.default_rng(2)
+    f = rng.integers(0, 256, (20, 30, 3), dtype=np.uint8)
+
+    def rec(**kw):
+        p = {k: D.identity_params(1)[0][k] for k in D.AUG_DTYPE.names}
+        p = {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in p.items()}
+        p.update(kw)
+        return p
+    assert np.array_equal(AO.augment_one(f, rec()), f)
+    out = AO.augment_one(f, rec(rbc_on=1, alpha=1.1, beta255=-12.75))
+    want = np.clip(f.astype(np.float32) * np.float32(1.1) + np.float32(-12.75), 0, 255).astype(np.uint8)
+    assert np.array_equal(out, want)
+    # HSV with zero shifts only re-quantises through 8-bit HSV (half-degree hue): a few grey levels
+    out = AO.augment_one(f, rec(hsv_on=1))
+    assert np.abs(out.astype(int) - f.astype(int)).max() <= 5
+    grey = np.full((4, 4, 3), 77, np.uint8)
+    assert np.array_equal(AO.augment_one(grey, rec(hsv_on=1, hue=7.0)), grey)   # hue of grey: no-op
+    # blur keeps constants, dropout zeroes its rectangle only
+    assert np.array_equal(AO.augment_one(grey, rec(blur_k=5, blur_w=D.gaussian_taps(5, 1.3).tolist())), grey)
+    out = AO.augment_one(f, rec(nholes=1, hole_y0=[2, 0, 0], hole_x0=[3, 0, 0], hole_y1=[6, 0, 0],
+                                hole_x1=[9, 0, 0]))
+    assert (out[2:6, 3:9] == 0).all() and np.array_equal(out[6:], f[6:])
+    n = AO.gaussian_noise(1234, 200000)
+    assert abs(float(n.mean())) < 0.01 and abs(float(n.std()) - 1.0) < 0.01
+    t = D.gaussian_taps(5, 2.0)
+    assert abs(t[0] + 2 * t[1] + 2 * t[2] - 1.0) < 1e-6
+    # the drawn parameter distribution follows the Compose probabilities (notebook.ipynb:387-394)
+    p = D.draw_aug_params(np.random.default_rng(0), 4000)
+    for field, prob in (("rbc_on", 0.5), ("hsv_on", 0.3)):
+        assert abs(p[field].mean() - prob) < 0.03
+    assert abs((p["blur_k"] > 1).mean() - 0.2) < 0.03 and abs((p["nholes"] > 0).mean() - 0.2) < 0.03
+    assert abs((p["noise_std255"] > 0).mean() - 0.3) < 0.03
+    assert p["alpha"].min() >= 0.8 and p["alpha"].max() <= 1.2 and np.abs(p["hue"]).max() <= 10
+    D.check_params(p, 88, 200)
