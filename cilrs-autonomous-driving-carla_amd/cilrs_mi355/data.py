@@ -15,7 +15,6 @@ import ctypes as C
 import os
 import queue
 import threading
-from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 import torch
@@ -61,31 +60,37 @@ def draw_aug_params(rng: np.random.Generator, batch: int, height: int = IMG_HEIG
     GaussianBlur(blur_limit=(3,5), p=.2), GaussNoise(std_range=(.02,.06), p=.3),
     CoarseDropout(1-3 holes, h 4-10, w 8-20, fill 0, p=.2)."""
     p = identity_params(batch)
-    for i in range(batch):
-        if rng.random() < 0.5:
-            p["rbc_on"][i] = 1
-            p["alpha"][i] = 1.0 + rng.uniform(-0.2, 0.2)
-            p["beta255"][i] = rng.uniform(-0.2, 0.2) * 255.0
-        if rng.random() < 0.3:
-            p["hsv_on"][i] = 1
-            p["hue"][i] = rng.uniform(-10, 10)
-            p["sat"][i] = rng.uniform(-20, 20)
-            p["val"][i] = rng.uniform(-15, 15)
-        if rng.random() < 0.2:
-            k = int(rng.choice((3, 5)))
-            p["blur_k"][i] = k
-            p["blur_w"][i] = gaussian_taps(k, rng.uniform(0.5, 3.0))
-        if rng.random() < 0.3:
-            p["noise_std255"][i] = rng.uniform(0.02, 0.06) * 255.0
-            p["noise_seed"][i] = rng.integers(0, 1 << 63, dtype=np.uint64)
-        if rng.random() < 0.2:
-            n = int(rng.integers(1, 4))
-            p["nholes"][i] = n
-            for k in range(n):
-                hh, ww = int(rng.integers(4, 11)), int(rng.integers(8, 21))
-                y0, x0 = int(rng.integers(0, height - hh + 1)), int(rng.integers(0, width - ww + 1))
-                p["hole_y0"][i, k], p["hole_x0"][i, k] = y0, x0
-                p["hole_y1"][i, k], p["hole_x1"][i, k] = y0 + hh, x0 + ww
+    on = rng.random((5, batch))
+    m = on[0] < 0.5
+    p["rbc_on"] = m
+    p["alpha"] = np.where(m, 1.0 + rng.uniform(-0.2, 0.2, batch), 1.0)
+    p["beta255"] = np.where(m, rng.uniform(-0.2, 0.2, batch) * 255.0, 0.0)
+    m = on[1] < 0.3
+    p["hsv_on"] = m
+    p["hue"] = np.where(m, rng.uniform(-10, 10, batch), 0.0)
+    p["sat"] = np.where(m, rng.uniform(-20, 20, batch), 0.0)
+    p["val"] = np.where(m, rng.uniform(-15, 15, batch), 0.0)
+    m = on[2] < 0.2
+    ks = rng.choice((3, 5), batch)
+    sig = rng.uniform(0.5, 3.0, batch)
+    for i in np.nonzero(m)[0]:
+        p["blur_k"][i] = ks[i]
+        p["blur_w"][i] = gaussian_taps(int(ks[i]), float(sig[i]))
+    m = on[3] < 0.3
+    p["noise_std255"] = np.where(m, rng.uniform(0.02, 0.06, batch) * 255.0, 0.0)
+    p["noise_seed"] = np.where(m, rng.integers(0, 1 << 63, batch, dtype=np.uint64), np.uint64(0))
+    m = on[4] < 0.2
+    nh = rng.integers(1, 4, batch)
+    hh = rng.integers(4, 11, (batch, 3))
+    ww = rng.integers(8, 21, (batch, 3))
+    y0 = (rng.random((batch, 3)) * (height - hh + 1)).astype(np.int64)
+    x0 = (rng.random((batch, 3)) * (width - ww + 1)).astype(np.int64)
+    live = m[:, None] & (np.arange(3)[None, :] < nh[:, None])
+    p["nholes"] = np.where(m, nh, 0)
+    p["hole_y0"] = np.where(live, y0, 0)
+    p["hole_x0"] = np.where(live, x0, 0)
+    p["hole_y1"] = np.where(live, y0 + hh, 0)
+    p["hole_x1"] = np.where(live, x0 + ww, 0)
     return p
 
 
@@ -190,14 +195,48 @@ class BatchLoader:
     JPEGs are decoded by `workers` threads into pinned memory one batch ahead of the consumer."""
 
     def __init__(self, sessions: Sessions, indices, batch_size: int, device, train: bool,
-                 seed: int = 0, workers: int = 8, height: int = IMG_HEIGHT, width: int = IMG_WIDTH):
+                 seed: int = 0, workers: int = 8, height: int = IMG_HEIGHT, width: int = IMG_WIDTH,
+                 processes: bool = False):
+        """processes=True decodes in `workers` spawned processes (no GIL contention: what a
+        B=128 / 14 ms training step needs); the default thread pool starts instantly."""
         self.s, self.idx = sessions, np.asarray(indices)
         self.bs, self.device, self.train = batch_size, torch.device(device), train
         self.h, self.w = height, width
         self.rng = np.random.default_rng(seed)
         self.gen = torch.Generator().manual_seed(seed)
-        self.pool = ThreadPoolExecutor(max_workers=max(1, workers))
+        self.workers = max(1, workers)
+        self.processes = processes
+        self.pool = None
+        self._slots = None
         self.weights = class_balanced_weights(sessions.command[self.idx]) if train else None
+
+    def _ensure_pool(self):
+        if self.pool is None:
+            if self.processes:
+                import multiprocessing as mp
+                self.pool = mp.get_context("spawn").Pool(self.workers)
+            else:
+                from multiprocessing.pool import ThreadPool
+                self.pool = ThreadPool(self.workers)
+        return self.pool
+
+    def close(self):
+        if self.pool is not None:
+            self.pool.terminate()
+            self.pool.join()
+            self.pool = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def __len__(self):
         n = len(self.idx)
@@ -209,31 +248,50 @@ class BatchLoader:
             return self.idx[pick]
         return self.idx
 
-    def _stage(self, ids):
-        """decode one batch into a fresh pinned buffer (worker threads; PIL releases the GIL)"""
-        host = torch.empty(len(ids), self.h, self.w, 3, dtype=torch.uint8).pin_memory()
-        view = host.numpy()
-
-        def one(k):
-            img = decode_jpeg(self.s.paths[ids[k]])
-            if img.shape != (self.h, self.w, 3):
-                raise RuntimeError(f"{self.s.paths[ids[k]]}: expected {self.w}x{self.h} RGB, got "
-                                   f"{img.shape}")
-            view[k] = img
-        list(self.pool.map(one, range(len(ids))))
-        params = draw_aug_params(self.rng, len(ids), self.h, self.w) if self.train \
-            else identity_params(len(ids))
-        return host, params, ids
-
     def __iter__(self):
+        try:
+            from cilrs_jpeg_worker import decode_chunk
+        except ImportError:          # the worker module sits next to the package directory
+            import sys
+            sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            from cilrs_jpeg_worker import decode_chunk
         order = self._order()
         nb = len(self)
-        q: queue.Queue = queue.Queue(maxsize=2)
+        q: queue.Queue = queue.Queue(maxsize=3)
+        pool = self._ensure_pool()
+        chunk = max(4, -(-self.bs // self.workers))
+        batches = [order[b * self.bs:(b + 1) * self.bs] for b in range(nb)]
+
+        def tasks():              # every batch cut into per-worker chunks, in order
+            for ids in batches:
+                for c in range(0, len(ids), chunk):
+                    yield (list(self.s.paths[ids[c:c + chunk]]), self.h, self.w)
+
+        # ring of pinned staging buffers, allocated (and touched) once: a fresh pinned allocation
+        # costs ~15 ms and its first DMA another ~17 ms on this platform (tools/loader_probe.py)
+        if self._slots is None:
+            self._slots = []
+            for _ in range(4):
+                t = torch.zeros(self.bs, self.h, self.w, 3, dtype=torch.uint8).pin_memory()
+                self._slots.append((t, t.numpy()))
+        free: queue.Queue = queue.Queue()
+        for k in range(len(self._slots)):
+            free.put(k)
 
         def producer():
             try:
-                for b in range(nb):
-                    q.put(self._stage(order[b * self.bs:(b + 1) * self.bs]))
+                results = pool.imap(decode_chunk, tasks())       # ordered, workers run ahead
+                for ids in batches:
+                    slot = free.get()
+                    view = self._slots[slot][1]
+                    k = 0
+                    while k < len(ids):
+                        part = next(results)
+                        view[k:k + len(part)] = part
+                        k += len(part)
+                    params = draw_aug_params(self.rng, len(ids), self.h, self.w) if self.train \
+                        else identity_params(len(ids))
+                    q.put((slot, params, ids))
                 q.put(None)
             except Exception as e:          # surface decode errors in the consumer
                 q.put(e)
@@ -244,10 +302,17 @@ class BatchLoader:
                 return
             if isinstance(item, Exception):
                 raise item
-            host, params, ids = item
-            frames = host.to(self.device, non_blocking=True)
+            slot, params, ids = item
+            n = len(ids)
+            frames = torch.empty(n, self.h, self.w, 3, dtype=torch.uint8, device=self.device)
+            frames.copy_(self._slots[slot][0][:n], non_blocking=True)
+            copied = torch.cuda.Event()
+            copied.record()
             img = augment_u8(frames, params)
-            yield (img,
-                   torch.from_numpy(self.s.speed[ids]).to(self.device, non_blocking=True),
-                   torch.from_numpy(self.s.command[ids]).to(self.device, non_blocking=True),
-                   torch.from_numpy(self.s.targets[ids]).to(self.device, non_blocking=True))
+            batch = (img,
+                     torch.from_numpy(self.s.speed[ids]).to(self.device, non_blocking=True),
+                     torch.from_numpy(self.s.command[ids]).to(self.device, non_blocking=True),
+                     torch.from_numpy(self.s.targets[ids]).to(self.device, non_blocking=True))
+            copied.synchronize()            # the staging slot may be refilled now
+            free.put(slot)
+            yield batch

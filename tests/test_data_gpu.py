@@ -111,6 +111,10 @@ def test_loader_end_to_end_and_train_step(tmp_path):
         assert np.isfinite(trainer.losses()["total"])
         nb += 1
     assert nb == len(train)
+    # process-pool decoding (the production setting) yields the same batches as the thread pool
+    with D.BatchLoader(s, va_idx, 2, dev, False, workers=2, processes=True) as pv:
+        for (ia, _, ca, _), (ib, _, cb, _) in zip(pv, D.BatchLoader(s, va_idx, 2, dev, False)):
+            assert torch.equal(ia, ib) and torch.equal(ca, cb)
     # same seed -> same sample order and augmentation parameters
     a = [c.cpu() for _, _, c, _ in D.BatchLoader(s, tr_idx, 4, dev, True, seed=5)]
     b = [c.cpu() for _, _, c, _ in D.BatchLoader(s, tr_idx, 4, dev, True, seed=5)]
