@@ -524,6 +524,103 @@ __device__ __forceinline__ int out_pixel(const ConvArgs& a, int m, int HoWo) {
 // Sum split-K partials (fixed order => deterministic) and apply the epilogue.  VEC = 4: one float4
 // per thread; VEC = 1: one float per thread (small problems: 4x the threads).  Four independent
 // load streams over the splits.
+// Split-K reduce that also emits the BatchNorm column partials of the finished tensor (dense
+// output only), so a split-K convolution needs no separate column-reduce pass:
+//   MODE 0 (forward):  partial = sum(v), sum(v*v) over the block's rows
+//   MODE 1 (data gradient): partial = sum(g), sum(g * xhat), g = v * (z > 0), xhat = (y-mean)*rstd
+// Layout and determinism as bn_colreduce_kernel (channel-major partial[2][C][gridDim.x]).
+template <int MODE>
+__global__ __launch_bounds__(256) void splitk_reduce_cols_kernel(const ConvArgs a,
+                                                                 const float* __restrict__ part,
+                                                                 const int M, const int splits,
+                                                                 const int rows_per_block,
+                                                                 float* __restrict__ partial) {
+    __shared__ float red[2][256 * 4];
+    const int C = a.Cout;
+    const int tpr = C >> 2;                // threads per row (one float4 each)
+    const int rpi = 256 / tpr;             // rows per iteration
+    const int q = threadIdx.x % tpr, rsub = threadIdx.x / tpr;
+    const int co = q * 4;
+    const size_t slab = (size_t)M * a.y_ld;
+    const int row_end = min(M, (int)(blockIdx.x + 1) * rows_per_block);
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 mean = {0.f, 0.f, 0.f, 0.f}, rstd = {0.f, 0.f, 0.f, 0.f};
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f}, bias = {0.f, 0.f, 0.f, 0.f};
+    if (MODE == 1) {
+        mean = *reinterpret_cast<const f32x4*>(a.bwd_stats + co);
+        rstd = *reinterpret_cast<const f32x4*>(a.bwd_stats + C + co);
+    }
+    if (a.ch_scale) {
+        sc = *reinterpret_cast<const f32x4*>(a.ch_scale + co);
+        sh = *reinterpret_cast<const f32x4*>(a.ch_shift + co);
+    }
+    if (a.bias) bias = *reinterpret_cast<const f32x4*>(a.bias + co);
+    for (int m = blockIdx.x * rows_per_block + rsub; m < row_end; m += rpi) {
+        const size_t o = (size_t)m * a.y_ld + co;
+        f32x4 acc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        int sidx = 0;
+        for (; sidx + 3 < splits; sidx += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                acc[u] += *reinterpret_cast<const f32x4*>(part + (size_t)(sidx + u) * slab + o);
+        }
+        for (; sidx < splits; ++sidx)
+            acc[0] += *reinterpret_cast<const f32x4*>(part + (size_t)sidx * slab + o);
+        f32x4 v = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        if (a.ch_scale) v = v * sc + sh;
+        if (a.bias) v += bias;
+        if (a.relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (a.mask) {
+            const f32x4 mk = *reinterpret_cast<const f32x4*>(a.mask + (size_t)m * a.mask_ld + co);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = mk[e] > 0.f ? v[e] * a.mask_scale : 0.f;
+        }
+        if (a.addend) v += *reinterpret_cast<const f32x4*>(a.addend + o);
+        if (a.relu_post) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        *reinterpret_cast<f32x4*>(a.y + o) = v;
+        if (MODE == 0) {
+            s1 += v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s2[e] = fmaf(v[e], v[e], s2[e]);
+        } else {
+            f32x4 g = v;
+            if (a.bwd_relu) {
+                const f32x4 zz = *reinterpret_cast<const f32x4*>(a.bwd_z + o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] = zz[e] > 0.f ? g[e] : 0.f;
+            }
+            const f32x4 yy = *reinterpret_cast<const f32x4*>(a.bwd_y + o);
+            s1 += g;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s2[e] = fmaf(g[e], (yy[e] - mean[e]) * rstd[e], s2[e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        red[0][threadIdx.x * 4 + e] = s1[e];
+        red[1][threadIdx.x * 4 + e] = s2[e];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float a1 = 0.f, a2 = 0.f;
+        const int qq = c >> 2, e = c & 3;
+        for (int rs = 0; rs < rpi; ++rs) {
+            a1 += red[0][(rs * tpr + qq) * 4 + e];
+            a2 += red[1][(rs * tpr + qq) * 4 + e];
+        }
+        partial[(size_t)c * gridDim.x + blockIdx.x] = a1;
+        partial[(size_t)(C + c) * gridDim.x + blockIdx.x] = a2;
+    }
+}
+
 template <int VEC>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvArgs a, const float* part,
                                                             const int M, const int splits) {
@@ -747,11 +844,26 @@ int launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
             if (!inkernel) a.tile_counters = nullptr;
         }
     }
-    if (a_in.bn_nblk)
-        *a_in.bn_nblk = (a.bn_partial && (a.splitk == 1 || inkernel)) ? cdiv(M, kCfg[ch.cfg].bm) : 0;
     const bool dense_out = a.out_sh == 1 && a.out_sw == 1 && a.out_H == a.Ho && a.out_W == a.Wo;
+    // split-K + separate reduce: the reduce kernel can emit the BatchNorm column partials itself
+    // when the output is dense and the channel count tiles a 256-thread block
+    const int tpr = a.Cout >> 2;
+    const bool cols_ok = a.splitk > 1 && !inkernel && dense_out && a.Cout % 4 == 0 && tpr <= 256 &&
+                         256 % tpr == 0 && a.y_ld % 4 == 0 && (!a.mask || a.mask_ld % 4 == 0);
+    int cols_rows = 0, cols_nblk = 0;
+    if (cols_ok && (a.bn_partial || a.bwd_partial)) {
+        const int rpi = 256 / tpr;
+        cols_rows = cdiv(cdiv(M, 1024), rpi) * rpi;       // <= 1024 partial rows per channel
+        cols_nblk = cdiv(M, cols_rows);
+    }
+    float* const fwd_partial = a.bn_partial;
+    float* const bwd_partial = a.bwd_partial;
+    if (a_in.bn_nblk)
+        *a_in.bn_nblk = !a.bn_partial ? 0
+                        : (a.splitk == 1 || inkernel) ? cdiv(M, kCfg[ch.cfg].bm) : cols_nblk;
     if (!(a.splitk == 1 && dense_out)) a.bwd_partial = nullptr;
-    if (a_in.bwd_nblk) *a_in.bwd_nblk = a.bwd_partial ? cdiv(M, kCfg[ch.cfg].bm) : 0;
+    if (a_in.bwd_nblk)
+        *a_in.bwd_nblk = a.bwd_partial ? cdiv(M, kCfg[ch.cfg].bm) : (bwd_partial ? cols_nblk : 0);
     float* final_y = a.y;
     if (a.splitk > 1 && !inkernel) a.y = a.scratch;      // legacy: partials + separate reduce
 
@@ -777,7 +889,13 @@ int launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
         const float* part = a.scratch;
         a.y = final_y;
         const size_t total4 = (size_t)M * (a.Cout / 4);
-        if (total4 < 65536) {        // small problem: one float per thread, 4x the parallelism
+        if (cols_nblk > 0 && fwd_partial) {
+            splitk_reduce_cols_kernel<0><<<cols_nblk, 256, 0, s>>>(a, part, M, a.splitk, cols_rows,
+                                                                   fwd_partial);
+        } else if (cols_nblk > 0 && bwd_partial) {
+            splitk_reduce_cols_kernel<1><<<cols_nblk, 256, 0, s>>>(a, part, M, a.splitk, cols_rows,
+                                                                   bwd_partial);
+        } else if (total4 < 65536) {  // small problem: one float per thread, 4x the parallelism
             const size_t total = total4 * 4;
             splitk_reduce_kernel<1><<<(int)((total + 255) / 256), 256, 0, s>>>(a, part, M, a.splitk);
         } else {

@@ -98,4 +98,6 @@ def test_two_rank_train_step_matches_oracle_dp_semantics(tmp_path):
         assert int((err > 2e-5).sum()) <= max(4, int(0.6 * err.numel())), n
     # rank 1's BN statistics followed ITS shard
     want_rm1 = reps[1].state_dict()["visual_encoder.1.running_mean"]
-    assert (sd1["visual_encoder.1.running_mean"] - want_rm1).abs().max() <= 1e-5
+    # (step 2 starts from parameters that differ by Adam's lr*sign(g) ambiguity: 1e-4, not 1e-5)
+    assert (sd1["visual_encoder.1.running_mean"] - want_rm1).abs().max() <= 1e-4
+    assert (sd0["visual_encoder.1.running_mean"] - want_rm1).abs().max() > 1e-3
