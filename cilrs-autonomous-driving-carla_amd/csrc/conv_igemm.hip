@@ -125,6 +125,28 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a, co
     const int cin_tiles = TAP_UNIFORM ? (a.Cin / BK) : 1;
     const float* zero = g_zero_page + kq * 4;
 
+    // Register-staged uniform path: buffer loads (wave-uniform base + 32-bit byte offset; a row
+    // whose tap falls outside the image gets offset ~0 = out of range = hardware returns zeros),
+    // and the per-tap offsets live one per lane and are fetched with v_readlane -- no scalar
+    // memory access and no pointer select inside the K loop.
+    constexpr bool BUF = TAP_UNIFORM && !DMA;
+    __amdgpu_buffer_rsrc_t rsA, rsB;
+    unsigned rowOff[A_PASSES], wOff[B_PASSES];
+    int tapA_v = 0, tapB_v = 0;
+    if constexpr (BUF) {
+        const size_t xbytes = (size_t)a.N * a.H * a.W * a.x_ld * sizeof(float);
+        rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)(unsigned)xbytes, 0x00020000);
+        rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, -1, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < A_PASSES; ++i) rowOff[i] = (unsigned)(rowBase[i] * 4);
+#pragma unroll
+        for (int i = 0; i < B_PASSES; ++i) wOff[i] = (unsigned)(wBase[i] * 4);
+        if (lane < a.ntaps) {
+            tapA_v = (a.tap_dh[lane] * a.W + a.tap_dw[lane]) * a.x_ld * 4;
+            tapB_v = a.tap_w[lane] * (W_MODE == 0 ? a.Cin : a.w_cin) * 4;
+        }
+    }
+
     // scalar cursor (tap, cin chunk) of the NEXT tile to load
     int ld_tap = kt_begin / cin_tiles;
     int ld_c = kt_begin - ld_tap * cin_tiles;
@@ -158,7 +180,24 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a, co
         }
     };
     auto load_tile = [&](f32x4(&ra)[A_PASSES], f32x4(&rb)[B_PASSES]) {
-        if constexpr (TAP_UNIFORM) {
+        if constexpr (BUF) {
+            const unsigned toff = (unsigned)__builtin_amdgcn_readlane(tapA_v, ld_tap) +
+                                  (unsigned)(ld_c * BK * 4);
+            const unsigned bit = 1u << ld_tap;
+#pragma unroll
+            for (int i = 0; i < A_PASSES; ++i) {
+                const unsigned off = (rowMask[i] & bit) ? rowOff[i] + toff : 0xFFFFFFFFu;
+                ra[i] = __builtin_bit_cast(
+                    f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)off, 0, 0));
+            }
+            unsigned koff = (unsigned)__builtin_amdgcn_readlane(tapB_v, ld_tap);
+            if constexpr (W_MODE == 0) koff += (unsigned)(ld_c * BK * 4);
+            else koff += (unsigned)(ld_c * BK) * (unsigned)(wrow * 4);
+#pragma unroll
+            for (int i = 0; i < B_PASSES; ++i)
+                rb[i] = __builtin_bit_cast(
+                    f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)(wOff[i] + koff), 0, 0));
+        } else if constexpr (TAP_UNIFORM) {
             const long toff = ((long)a.tap_dh[ld_tap] * a.W + a.tap_dw[ld_tap]) * a.x_ld +
                               ld_c * BK;
 #pragma unroll
@@ -228,34 +267,50 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a, co
     auto compute = [&](int buf) {
         const float* Ab = As + buf * BM * APIT + (wm * WTM + l31) * APIT;
         const float* Bb = Bs + buf * B_FLOATS;
-#pragma unroll
-        for (int q = 0; q < BK / 8; ++q) {
-            f32x4 af[TM], bf[TN];
+        // operand fragments of k-group q+1 are read from LDS while group q is multiplied
+        f32x4 af[2][TM], bf[2][TN];
+        auto frags = [&](int q, f32x4(&fa)[TM], f32x4(&fb)[TN]) {
             const int chunk = DMA ? (((2 * q + lh) ^ swz) * 4) : (q * 8 + lh * 4);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * APIT + chunk);
+                fa[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * APIT + chunk);
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 if constexpr (W_MODE == 0) {
-                    bf[j] = *reinterpret_cast<const f32x4*>(
+                    fb[j] = *reinterpret_cast<const f32x4*>(
                         Bb + (wn * WTN + j * 32 + l31) * APIT + chunk);
                 } else {
                     const float* p = Bb + (q * 8 + lh * 4) * BPITCH1 + wn * WTN + j * 32 + l31;
-                    bf[j][0] = p[0];
-                    bf[j][1] = p[BPITCH1];
-                    bf[j][2] = p[2 * BPITCH1];
-                    bf[j][3] = p[3 * BPITCH1];
+                    fb[j][0] = p[0];
+                    fb[j][1] = p[BPITCH1];
+                    fb[j][2] = p[2 * BPITCH1];
+                    fb[j][3] = p[3 * BPITCH1];
                 }
             }
+        };
+        frags(0, af[0], bf[0]);
+#pragma unroll
+        for (int q = 0; q < BK / 8; ++q) {
+            if (q + 1 < BK / 8) frags(q + 1, af[(q + 1) & 1], bf[(q + 1) & 1]);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e],
-                                                                         acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                            af[q & 1][i][e], bf[q & 1][j][e], acc[i][j], 0, 0, 0);
+        }
+        // pin the interleave (the scheduler otherwise sinks every read to just before its use
+        // and the wave eats one LDS round trip per k-group): reads of groups 0 and 1, then
+        // [multiply group q | read group q+2] ...
+        constexpr int NR = TM + (W_MODE == 0 ? TN : 4 * TN);      // LDS reads per k-group
+        constexpr int NM = 4 * TM * TN;                           // MFMAs per k-group
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * NR, 0);
+#pragma unroll
+        for (int q = 0; q < BK / 8; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+            if (q + 2 < BK / 8) __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
         }
     };
 
@@ -280,11 +335,35 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a, co
     } else {
     // ---- main loop: loads run two tiles ahead (register sets 0/1), LDS double-buffered ----
     f32x4 ra0[A_PASSES], rb0[B_PASSES], ra1[A_PASSES], rb1[B_PASSES];
-    if (nt > 0) load_tile(ra0, rb0);
-    if (nt > 1) load_tile(ra1, rb1);
-    if (nt > 0) store_tile(0, ra0, rb0);
-    __syncthreads();
-    for (int it = 0; it < nt; it += 2) {
+    int it = 0;
+    if (nt >= 4) {
+        // steady state: tiles it+2 and it+3 exist, so every load / LDS store -- here and in this
+        // prologue -- is unconditional and the compiler's wait counts are exact (one guarded
+        // store anywhere on the path makes it re-wait for the in-flight register set at the top
+        // of every iteration, which halves the prefetch distance)
+        load_tile(ra0, rb0);
+        load_tile(ra1, rb1);
+        store_tile(0, ra0, rb0);
+        __syncthreads();
+        for (; it + 3 < nt; it += 2) {
+            load_tile(ra0, rb0);
+            __builtin_amdgcn_sched_barrier(0);   // issue the loads BEFORE the multiplies: two
+            compute(0);                          // compute phases of latency cover, not one
+            store_tile(1, ra1, rb1);
+            __syncthreads();
+            load_tile(ra1, rb1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(1);
+            store_tile(0, ra0, rb0);
+            __syncthreads();
+        }
+    } else {
+        if (nt > 0) load_tile(ra0, rb0);
+        if (nt > 1) load_tile(ra1, rb1);
+        if (nt > 0) store_tile(0, ra0, rb0);
+        __syncthreads();
+    }
+    for (; it < nt; it += 2) {
         if (it + 2 < nt) load_tile(ra0, rb0);
         compute(0);
         if (it + 1 < nt) store_tile(1, ra1, rb1);
