@@ -23,7 +23,7 @@ namespace {
 
 constexpr int BKP = 32;   // pixels per K-tile
 
-template <int BT, bool TAP_UNIFORM>
+template <int BT, bool TAP_UNIFORM, bool PIN>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a, const int Mpix,
                                                             const int splits, const int tiles_ci,
                                                             const int Ncols) {
@@ -87,21 +87,29 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a, c
         coh[i] = rem / a.Wo;
         cow[i] = rem - coh[i] * a.Wo;
     }
-    const float* dyq = a.dy + co0 + q * 4;
+    // buffer loads: wave-uniform base + 32-bit byte offset; a pixel past the end of dy is out of
+    // range by construction and a padded / out-of-image x pixel gets offset ~0, so the hardware
+    // returns zeros and the loads carry no branches
+    const __amdgpu_buffer_rsrc_t rsDy = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.dy, 0, (int)(unsigned)((size_t)Mpix * a.dy_ld * sizeof(float)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.x, 0, (int)(unsigned)((size_t)a.N * a.H * a.W * a.x_ld * sizeof(float)),
+        0x00020000);
+    const unsigned dyq = (unsigned)(co0 + q * 4) * 4u;
+    const unsigned dy_pitch = (unsigned)a.dy_ld * 4u;
 
     auto load_tile = [&](f32x4(&ra)[PASSES], f32x4(&rb)[PASSES]) {
 #pragma unroll
         for (int i = 0; i < PASSES; ++i) {
-            f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
-            if (cp[i] < Mpix) {
-                va = *reinterpret_cast<const f32x4*>(dyq + (size_t)cp[i] * a.dy_ld);
-                const int h = coh[i] * a.stride - a.pad + kh, w = cow[i] * a.stride - a.pad + kw;
-                if (col_ok && h >= 0 && w >= 0 && h < a.H && w < a.W)
-                    vb = *reinterpret_cast<const f32x4*>(
-                        a.x + (size_t)((cn[i] * a.H + h) * a.W + w) * a.x_ld + ci);
-            }
-            ra[i] = va;
-            rb[i] = vb;
+            const int h = coh[i] * a.stride - a.pad + kh, w = cow[i] * a.stride - a.pad + kw;
+            const bool ok = col_ok && cp[i] < Mpix && h >= 0 && w >= 0 && h < a.H && w < a.W;
+            const unsigned xo =
+                ok ? (unsigned)(((cn[i] * a.H + h) * a.W + w) * a.x_ld + ci) * 4u : 0xFFFFFFFFu;
+            ra[i] = __builtin_bit_cast(
+                f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                           rsDy, (int)((unsigned)cp[i] * dy_pitch + dyq), 0, 0));
+            rb[i] = __builtin_bit_cast(
+                f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)xo, 0, 0));
             // advance the cursor by BKP pixels
             cp[i] += BKP;
             cow[i] += dow;
@@ -145,6 +153,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a, c
                 acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.x, acc[1][0], 0, 0, 0);
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[1][1], 0, 0, 0);
             }
+            // pin the LDS reads two steps ahead of the MFMAs that use them
+            if constexpr (PIN) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+                for (int s = 0; s < BKP / 2; ++s) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                    if (s + 2 < BKP / 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                }
+            }
         } else {
             const float* Ab = As + buf * BKP * PITCH + lh * PITCH + wm * WT + l31;
             const float* Bb = Bs + buf * BKP * PITCH + lh * PITCH + wn * WT + l31;
@@ -153,16 +170,46 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a, c
                 const float af = Ab[2 * s * PITCH], bf = Bb[2 * s * PITCH];
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[0][0], 0, 0, 0);
             }
+            if constexpr (PIN) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+                for (int s = 0; s < BKP / 2; ++s) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (s + 4 < BKP / 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                }
+            }
         }
     };
 
     // loads run two K-tiles ahead of the MFMAs (see conv_igemm.hip)
     f32x4 ra0[PASSES], rb0[PASSES], ra1[PASSES], rb1[PASSES];
-    if (nt > 0) load_tile(ra0, rb0);
-    if (nt > 1) load_tile(ra1, rb1);
-    if (nt > 0) store_tile(0, ra0, rb0);
-    __syncthreads();
-    for (int it = 0; it < nt; it += 2) {
+    int it = 0;
+    if (nt >= 4) {
+        // branch-free steady state (see conv_igemm.hip): exact wait counts, loads issued before
+        // the multiplies they hide behind
+        load_tile(ra0, rb0);
+        load_tile(ra1, rb1);
+        store_tile(0, ra0, rb0);
+        __syncthreads();
+        for (; it + 3 < nt; it += 2) {
+            load_tile(ra0, rb0);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(0);
+            store_tile(1, ra1, rb1);
+            __syncthreads();
+            load_tile(ra1, rb1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(1);
+            store_tile(0, ra0, rb0);
+            __syncthreads();
+        }
+    } else {
+        if (nt > 0) load_tile(ra0, rb0);
+        if (nt > 1) load_tile(ra1, rb1);
+        if (nt > 0) store_tile(0, ra0, rb0);
+        __syncthreads();
+    }
+    for (; it < nt; it += 2) {
         if (it + 2 < nt) load_tile(ra0, rb0);
         compute(0);
         if (it + 1 < nt) store_tile(1, ra1, rb1);
@@ -292,22 +339,35 @@ int launch_conv_wgrad(const WgradArgs& a, hipStream_t s) {
     const int Mpix = a.N * a.Ho * a.Wo;
     dim3 grid(p.ntiles, a.Cout / p.bt, p.splits);
     const size_t lds = (size_t)4 * BKP * (p.bt + 4) * sizeof(float);
+    // CILRS_WGRAD_PIN=0: let the compiler place the LDS reads (A/B switch for tools/conv_bench.py)
+    static const bool pin = getenv("CILRS_WGRAD_PIN") ? atoi(getenv("CILRS_WGRAD_PIN")) != 0 : true;
     if (p.bt == 128) {
         static bool attr = false;
         if (!attr) {
             CILRS_HIP(hipFuncSetAttribute(
-                reinterpret_cast<const void*>(&conv_wgrad_kernel<128, true>),
+                reinterpret_cast<const void*>(&conv_wgrad_kernel<128, true, true>),
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            CILRS_HIP(hipFuncSetAttribute(
+                reinterpret_cast<const void*>(&conv_wgrad_kernel<128, true, false>),
                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr = true;
         }
-        conv_wgrad_kernel<128, true><<<grid, 256, lds, s>>>(a, Mpix, p.splits, p.tiles_ci,
-                                                            p.ncols);
+        if (pin)
+            conv_wgrad_kernel<128, true, true><<<grid, 256, lds, s>>>(a, Mpix, p.splits,
+                                                                      p.tiles_ci, p.ncols);
+        else
+            conv_wgrad_kernel<128, true, false><<<grid, 256, lds, s>>>(a, Mpix, p.splits,
+                                                                       p.tiles_ci, p.ncols);
     } else if (p.uniform) {
-        conv_wgrad_kernel<64, true><<<grid, 256, lds, s>>>(a, Mpix, p.splits, p.tiles_ci,
-                                                           p.ncols);
+        if (pin)
+            conv_wgrad_kernel<64, true, true><<<grid, 256, lds, s>>>(a, Mpix, p.splits,
+                                                                     p.tiles_ci, p.ncols);
+        else
+            conv_wgrad_kernel<64, true, false><<<grid, 256, lds, s>>>(a, Mpix, p.splits,
+                                                                      p.tiles_ci, p.ncols);
     } else {
-        conv_wgrad_kernel<64, false><<<grid, 256, lds, s>>>(a, Mpix, p.splits, p.tiles_ci,
-                                                            p.ncols);
+        conv_wgrad_kernel<64, false, false><<<grid, 256, lds, s>>>(a, Mpix, p.splits, p.tiles_ci,
+                                                                   p.ncols);
     }
     CILRS_LAUNCH_CHECK();
     const size_t n_src = (size_t)a.Cout * p.ncols;
