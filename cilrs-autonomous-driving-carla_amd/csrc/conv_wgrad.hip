@@ -247,18 +247,59 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a, c
     }
 }
 
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slabs, float* dw,
+// Sum the K-split slabs (fixed order => deterministic).  VEC = 4: float4 per thread, four
+// independent slab streams in flight, and for small outputs with many slabs (e.g. a 1x1
+// downsample: 8 K floats x 220 slabs) G thread groups share one output and combine through LDS so
+// the chip stays full.  VEC = 1 handles the channel-padded stem.
+template <int VEC>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs,
+                                                           float* __restrict__ dw,
                                                            const int splits, const size_t n_src,
                                                            const int cin, const int cin_dst,
-                                                           const int accumulate) {
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n_src;
-         idx += (size_t)gridDim.x * blockDim.x) {
-        const int ci = (int)(idx % cin);
-        if (ci >= cin_dst) continue;
-        float v = slabs[idx];
-        for (int s = 1; s < splits; ++s) v += slabs[(size_t)s * n_src + idx];
-        const size_t o = (idx / cin) * cin_dst + ci;
-        dw[o] = accumulate ? dw[o] + v : v;
+                                                           const int accumulate, const int G) {
+    if constexpr (VEC == 4) {
+        __shared__ f32x4 red[256];
+        const int opb = 256 / G;                       // outputs per block
+        const int g = threadIdx.x / opb, ol = threadIdx.x - g * opb;
+        const size_t nvec = n_src / 4;
+        const size_t iv = (size_t)blockIdx.x * opb + ol;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (iv < nvec) {
+            const float* base = slabs + iv * 4;
+            f32x4 acc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            int sidx = g;
+            for (; sidx + 3 * G < splits; sidx += 4 * G) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    acc[u] += *reinterpret_cast<const f32x4*>(base + (size_t)(sidx + u * G) * n_src);
+            }
+            for (; sidx < splits; sidx += G)
+                acc[0] += *reinterpret_cast<const f32x4*>(base + (size_t)sidx * n_src);
+            v = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        }
+        if (G > 1) {
+            red[threadIdx.x] = v;
+            __syncthreads();
+            if (g == 0) {
+                for (int k = 1; k < G; ++k) v += red[k * opb + ol];
+            }
+        }
+        if (g == 0 && iv < nvec) {
+            f32x4* o = reinterpret_cast<f32x4*>(dw + iv * 4);      // cin_dst == cin here
+            *o = accumulate ? *o + v : v;
+        }
+    } else {
+        for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n_src;
+             idx += (size_t)gridDim.x * blockDim.x) {
+            const int ci = (int)(idx % cin);
+            if (ci >= cin_dst) continue;
+            float v = slabs[idx];
+            for (int sp = 1; sp < splits; ++sp) v += slabs[(size_t)sp * n_src + idx];
+            const size_t o = (idx / cin) * cin_dst + ci;
+            dw[o] = accumulate ? dw[o] + v : v;
+        }
     }
 }
 
@@ -371,9 +412,18 @@ int launch_conv_wgrad(const WgradArgs& a, hipStream_t s) {
     }
     CILRS_LAUNCH_CHECK();
     const size_t n_src = (size_t)a.Cout * p.ncols;
-    const int blocks = (int)((n_src + 255) / 256 < 1024 ? (n_src + 255) / 256 : 1024);
-    wgrad_reduce_kernel<<<blocks, 256, 0, s>>>(a.slabs, a.dw, p.splits, n_src, a.Cin, a.Cin_dst,
-                                               a.accumulate);
+    if (a.Cin == a.Cin_dst && n_src % 4 == 0 && ((uintptr_t)a.dw & 15) == 0) {
+        const size_t nvec = n_src / 4;
+        int G = 1;                                    // thread groups per output (power of two)
+        while (G < 16 && nvec * G < 131072 && 8 * G <= p.splits) G *= 2;
+        const int opb = 256 / G;
+        wgrad_reduce_kernel<4><<<(int)((nvec + opb - 1) / opb), 256, 0, s>>>(
+            a.slabs, a.dw, p.splits, n_src, a.Cin, a.Cin_dst, a.accumulate, G);
+    } else {
+        const int blocks = (int)((n_src + 255) / 256 < 1024 ? (n_src + 255) / 256 : 1024);
+        wgrad_reduce_kernel<1><<<blocks, 256, 0, s>>>(a.slabs, a.dw, p.splits, n_src, a.Cin,
+                                                      a.Cin_dst, a.accumulate, 1);
+    }
     CILRS_LAUNCH_CHECK();
     return 0;
 }
