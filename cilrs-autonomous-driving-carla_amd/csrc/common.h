@@ -209,6 +209,26 @@ int launch_heads_small_pre(const float* feat, int HW, const float* speed, const 
 int launch_heads_small_layer(const HeadsSmallArgs& a, hipStream_t s);
 int launch_augment_u8(const unsigned char* frames, const cilrs_aug_params* params, int B, int H,
                       int W, float* out_f32, unsigned char* out_u8, hipStream_t s);
+// grouped small GEMMs of the heads (heads_gemm.hip): mode 0 NT (linear forward), 1 NN (input
+// gradient), 2 TN (weight + bias gradient); one launch covers up to five chains
+struct HGemmGroup {
+    const float* A; const float* B; float* C;
+    const float* bias;                 // NT: added per column (may be NULL)
+    const float* mask;                 // NN: activation, gradient kept where > 0 (may be NULL)
+    float* dbias;                      // TN: column sums of A (may be NULL)
+    unsigned long long drop_stream;    // NT: dropout stream id of this chain's layer (kNoDrop: none)
+    float mask_scale;                  // NN: factor applied where the mask is > 0
+    int M, N, K, lda, ldb, ldc, ldmask;
+    int vec;                           // set by the launcher
+};
+struct HGemmArgs {
+    HGemmGroup g[5];
+    int ngroups, relu, accumulate;
+    float drop_p;
+    unsigned long long seed;
+};
+constexpr unsigned long long kNoDrop = ~0ull;
+int launch_hgemm(int mode, HGemmArgs& a, hipStream_t s);
 constexpr int kEvalAccDoubles = 72;
 int launch_eval_accumulate(const float* pc, const float* tc, const float* ps, const float* ts,
                            const long long* cmd, int B, double* acc, float* steer_err,
