@@ -208,7 +208,7 @@ using namespace cilrs;
 // The plan
 // ------------------------------------------------------------------------------------------------
 struct ConvG { int H, W, Ho, Wo, M; size_t y, z, stats; };
-constexpr int kTileCounters = 16384, kHeadCounters = 1024;
+constexpr int kTileCounters = 16384;
 
 // dy ring: bn_bwd writes each conv's output gradient into the next ring slot; the weight-gradient
 // GEMM that consumes it runs on side stream 0 and may lag the data-gradient chain by up to
@@ -232,8 +232,7 @@ struct cilrs_net {
     size_t x4, w4, pool, argmax_b /*bytes offset*/, combined, s1, p1, p2, h1[4], h2[4], all_out;
     size_t dcombined, ds1, dp1, dp2, dh1[4], dh2[4], dcomb_part[5], d_all, speed_in,
         cmd_b /*bytes offset*/;
-    size_t hscr[5], hscr_floats, hslab[5], hslab_floats;   // per-chain scratch of the heads
-    size_t tile_cnt, hcnt[5];              // split-K ticket counters (ints; trunk / head chains)
+    size_t tile_cnt;                       // split-K ticket counters (ints)
     const void* cnt_zeroed_for = nullptr;  // workspace whose counters have been zeroed
     size_t G[kNumG];                       // gradient buffers: [1..3] fixed roles, the rest = dy ring
     size_t gmax;
@@ -244,8 +243,8 @@ struct cilrs_net {
     // chains) run concurrently so one launch's tail fills with another's blocks
     bool overlap = true;
     bool streams_ready = false;
-    hipStream_t side[5];
-    hipEvent_t fork_ev, join_ev[5], gbuf_ev[kNumG];
+    hipStream_t side[1];                   // weight-gradient stream
+    hipEvent_t fork_ev, gbuf_ev[kNumG];
     bool gbuf_pending[kNumG] = {};
     int dy_pos = 0;
     int bwd_nblk_next = 0;                 // fused BN-backward partials waiting for their BN
@@ -296,8 +295,6 @@ int zero_counters_once(cilrs_net* net, void* workspace, hipStream_t s) {
     if (net->cnt_zeroed_for == workspace) return 0;
     float* ws = reinterpret_cast<float*>(workspace);
     CILRS_HIP(hipMemsetAsync(ws + net->tile_cnt, 0, kTileCounters * sizeof(int), s));
-    for (int k = 0; k < 5; ++k)
-        CILRS_HIP(hipMemsetAsync(ws + net->hcnt[k], 0, kHeadCounters * sizeof(int), s));
     net->cnt_zeroed_for = workspace;
     return 0;
 }
@@ -309,13 +306,10 @@ int ensure_streams(cilrs_net* net) {
     // side stream 0 carries the weight-gradient GEMMs (CILRS_SIDE_PRIO=1: lowest priority -- an
     // experiment that starves them, see kDyRing)
     static const int side_prio = getenv("CILRS_SIDE_PRIO") ? atoi(getenv("CILRS_SIDE_PRIO")) : 0;
-    for (int i = 0; i < 5; ++i) {
-        if (i == 0 && side_prio)
-            CILRS_HIP(hipStreamCreateWithPriority(&net->side[i], hipStreamNonBlocking, prio_least));
-        else
-            CILRS_HIP(hipStreamCreateWithFlags(&net->side[i], hipStreamNonBlocking));
-        CILRS_HIP(hipEventCreateWithFlags(&net->join_ev[i], hipEventDisableTiming));
-    }
+    if (side_prio)
+        CILRS_HIP(hipStreamCreateWithPriority(&net->side[0], hipStreamNonBlocking, prio_least));
+    else
+        CILRS_HIP(hipStreamCreateWithFlags(&net->side[0], hipStreamNonBlocking));
     for (int i = 0; i < kNumG; ++i)
         CILRS_HIP(hipEventCreateWithFlags(&net->gbuf_ev[i], hipEventDisableTiming));
     CILRS_HIP(hipEventCreateWithFlags(&net->fork_ev, hipEventDisableTiming));
@@ -328,22 +322,6 @@ bool use_overlap(cilrs_net* net) {
     // then match the hipEvent brackets of the profile mode)
     static const int env = getenv("CILRS_OVERLAP") ? atoi(getenv("CILRS_OVERLAP")) : 1;
     return env != 0 && net->overlap && !net->prof.on;
-}
-// side streams [0,n) start after everything enqueued on `main` so far
-int fork_streams(cilrs_net* net, hipStream_t main, int n) {
-    if (!use_overlap(net)) return 0;
-    if (ensure_streams(net)) return 1;
-    CILRS_HIP(hipEventRecord(net->fork_ev, main));
-    for (int i = 0; i < n; ++i) CILRS_HIP(hipStreamWaitEvent(net->side[i], net->fork_ev, 0));
-    return 0;
-}
-int join_streams(cilrs_net* net, hipStream_t main, int n) {
-    if (!use_overlap(net)) return 0;
-    for (int i = 0; i < n; ++i) {
-        CILRS_HIP(hipEventRecord(net->join_ev[i], net->side[i]));
-        CILRS_HIP(hipStreamWaitEvent(main, net->join_ev[i], 0));
-    }
-    return 0;
 }
 hipStream_t side_or(cilrs_net* net, hipStream_t main, int i) {
     return use_overlap(net) ? net->side[i] : main;
@@ -447,60 +425,6 @@ int conv_wgrad(cilrs_net* net, const ConvT& c, const ConvG& g, const float* x, i
                                 (double)c.cout * c.k * c.k * c.cin);
     RUN(net, std::string("conv_wgrad.") + kGroupName[c.group], flops, bytes, s,
         launch_conv_wgrad(a, s));
-    return 0;
-}
-
-// wide linear layer on the matrix pipe: y[B][out] = relu?(x[B][in] W^T + b)
-int lin_fwd(cilrs_net* net, const LinT& l, const float* P, const float* x, int x_ld, float* y,
-            int y_ld, int relu, int chain, hipStream_t s) {
-    ConvArgs a;
-    memset(&a, 0, sizeof(a));
-    a.x = x; a.w = P + l.w; a.y = y; a.bias = P + l.b;
-    a.N = net->B; a.H = 1; a.W = 1; a.Cin = l.in; a.Ho = 1; a.Wo = 1; a.Cout = l.out;
-    a.KH = a.KW = 1; a.stride = 1; a.pad = 0;
-    a.x_ld = x_ld; a.y_ld = y_ld; a.w_mode = 0; a.w_cin = l.in; a.relu = relu;
-    a.scratch = net->ws_base + net->hscr[chain]; a.scratch_floats = net->hscr_floats;
-    a.tile_counters = reinterpret_cast<int*>(net->ws_base + net->hcnt[chain]);
-    a.tile_counters_cap = kHeadCounters;
-    a.force_cfg = -1;
-    RUN(net, "heads_fwd", 2.0 * net->B * l.in * l.out, 4.0 * l.in * l.out, s,
-        launch_conv_igemm(a, s));
-    return 0;
-}
-
-// dx[B][in] = (dy[B][out] W) [masked by act>0, scaled] [+ addend]
-int lin_dgrad(cilrs_net* net, const LinT& l, const float* P, const float* dy, int dy_ld,
-              float* dx, int dx_ld, const float* act, int act_ld, float act_scale,
-              const float* addend, int chain, hipStream_t s) {
-    DgradArgs a;
-    memset(&a, 0, sizeof(a));
-    a.dy = dy; a.w = P + l.w; a.dx = dx; a.addend = addend;
-    a.mask = act; a.mask_ld = act_ld; a.mask_scale = act_scale;
-    a.N = net->B; a.H = 1; a.W = 1; a.Cin = l.in; a.Ho = 1; a.Wo = 1; a.Cout = l.out;
-    a.K = 1; a.stride = 1; a.pad = 0;
-    a.dy_ld = dy_ld; a.dx_ld = dx_ld;
-    a.scratch = net->ws_base + net->hscr[chain]; a.scratch_floats = net->hscr_floats;
-    a.tile_counters = reinterpret_cast<int*>(net->ws_base + net->hcnt[chain]);
-    a.tile_counters_cap = kHeadCounters;
-    a.force_cfg = -1;
-    RUN(net, "heads_bwd", 2.0 * net->B * l.in * l.out, 4.0 * l.in * l.out, s,
-        launch_conv_dgrad(a, s));
-    return 0;
-}
-
-// dW[out][in] = dy^T x ; db = colsum(dy)
-int lin_wgrad(cilrs_net* net, const LinT& l, float* Gp, const float* x, int x_ld, const float* dy,
-              int dy_ld, float* ws, int chain, hipStream_t s) {
-    WgradArgs a;
-    memset(&a, 0, sizeof(a));
-    a.x = x; a.dy = dy; a.dw = Gp + l.w; a.slabs = ws + net->hslab[chain];
-    a.N = net->B; a.H = 1; a.W = 1; a.Cin = l.in; a.Ho = 1; a.Wo = 1; a.Cout = l.out;
-    a.KH = a.KW = 1; a.stride = 1; a.pad = 0;
-    a.x_ld = x_ld; a.dy_ld = dy_ld; a.Cin_dst = l.in; a.accumulate = 0;
-    CILRS_CHECK(wgrad_scratch_floats(a) <= net->hslab_floats, "wgrad scratch too small (heads)");
-    RUN(net, "heads_bwd", 2.0 * net->B * l.in * l.out, 4.0 * l.in * l.out, s,
-        launch_conv_wgrad(a, s));
-    RUN(net, "heads_bwd", 0.0, 0.0, s, launch_colsum(dy, Gp + l.b, net->B, l.out, dy_ld, 0, s));
     return 0;
 }
 
@@ -652,12 +576,6 @@ int cilrs_net_create(int batch, int height, int width, cilrs_net** out) {
         n->dh2[k] = bump.take((size_t)B * 256);
     }
     for (int k = 0; k < 5; ++k) n->dcomb_part[k] = bump.take((size_t)B * 640);
-    n->hscr_floats = (size_t)16 * B * 640;
-    n->hslab_floats = (size_t)2 * 256 * 640;
-    for (int k = 0; k < 5; ++k) {
-        n->hscr[k] = bump.take(n->hscr_floats);
-        n->hslab[k] = bump.take(n->hslab_floats);
-    }
     n->d_all = bump.take((size_t)4 * B * 4);
     n->speed_in = bump.take((size_t)B);
     n->cmd_b = bump.take((size_t)B * 2) * sizeof(float);
@@ -688,7 +606,6 @@ int cilrs_net_create(int batch, int height, int width, cilrs_net** out) {
     n->ksplit = bump.take(ksplit_max > 0 ? ksplit_max : 4);
     n->status_b = bump.take(64) * sizeof(float);
     n->tile_cnt = bump.take(kTileCounters);
-    for (int k = 0; k < 5; ++k) n->hcnt[k] = bump.take(kHeadCounters);
     n->bn_table.n = (int)A.convs.size();
     for (size_t ci = 0; ci < A.convs.size(); ++ci) {
         const BnT& b = A.bns[A.convs[ci].bn];
@@ -704,10 +621,7 @@ int cilrs_net_create(int batch, int height, int width, cilrs_net** out) {
 
 void cilrs_net_destroy(cilrs_net* net) {
     if (net && net->streams_ready) {
-        for (int i = 0; i < 5; ++i) {
-            (void)hipStreamDestroy(net->side[i]);
-            (void)hipEventDestroy(net->join_ev[i]);
-        }
+        (void)hipStreamDestroy(net->side[0]);
         for (int i = 0; i < kNumG; ++i) (void)hipEventDestroy(net->gbuf_ev[i]);
         (void)hipEventDestroy(net->fork_ev);
     }
