@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcilrs_hip.so")
+# CILRS_LIB: another build of the same library (A/B timing of kernel variants on one box)
+LIB_PATH = os.environ.get("CILRS_LIB") or os.path.join(_HERE, "libcilrs_hip.so")
 
 c_float_p = C.POINTER(C.c_float)
 vp = C.c_void_p
