@@ -260,6 +260,19 @@ def main():
         dt = (time.perf_counter() - t1) / 20
         out["infer_batch64"] = {"frames_per_s": round(64 / dt, 1), "ms_per_batch": round(dt * 1e3, 3),
                                 "dtype": "f32", "frames": 320}
+        # the same streams with the BasicBlock trunk in fp16 (BatchNorm folded, fp32 accumulate)
+        for i in range(5):
+            trainer.eng.run_forward_u8(u64[i], spd64, cmd64, half=True)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(4):
+            for i in range(5):
+                trainer.eng.run_forward_u8(u64[i], spd64, cmd64, half=True)
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t1) / 20
+        out["infer_batch64_f16"] = {"frames_per_s": round(64 / dt, 1),
+                                    "ms_per_batch": round(dt * 1e3, 3), "dtype": "f16 trunk",
+                                    "frames": 320}
         # device-side breakdown of one B=1 forward (eager launches, hipEvent per kernel)
         pl1 = trainer.eng.plan(1, 88, 200)
         pl1.profile_reset()

@@ -214,10 +214,11 @@ class Engine:
             pl.generation += 1
         return controls, pred_speed, pl
 
-    def run_forward_u8(self, frames_u8, speed, command, out=None, graph=False):
+    def run_forward_u8(self, frames_u8, speed, command, out=None, graph=False, half=False):
         """uint8 RGB HWC frames [B,H,W,3] -> eval forward with fused preprocessing.  With
         graph=True the launch sequence is replayed from a cached hipGraph (all tensors must keep
-        their addresses; the current stream must not be the default stream)."""
+        their addresses; the current stream must not be the default stream).  half=True runs the
+        BasicBlock trunk in fp16 (BatchNorm folded, fp32 accumulation): batched serving."""
         if frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4 or frames_u8.size(3) != 3:
             raise RuntimeError("frames must be uint8 [B,H,W,3]")
         b = frames_u8.size(0)
@@ -228,7 +229,10 @@ class Engine:
             pred_speed = torch.empty(b, dtype=torch.float32, device=self.device)
         else:
             controls, pred_speed = out
-        fn = L.lib().cilrs_net_forward_u8_graph if graph else L.lib().cilrs_net_forward_u8
+        if half and graph:
+            raise RuntimeError("run_forward_u8: half=True is an eager path")
+        fn = (L.lib().cilrs_net_forward_u8_f16 if half else
+              L.lib().cilrs_net_forward_u8_graph if graph else L.lib().cilrs_net_forward_u8)
         L.check(fn(pl.handle, C.byref(self.bufs[(pl.batch, pl.h, pl.w)]), L.ptr(frames_u8),
                    L.ptr(speed.contiguous()), L.ptr(command.contiguous()), L.ptr(controls),
                    L.ptr(pred_speed), self._stream()))

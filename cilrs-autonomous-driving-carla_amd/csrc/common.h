@@ -209,6 +209,31 @@ int launch_heads_small_pre(const float* feat, int HW, const float* speed, const 
 int launch_heads_small_layer(const HeadsSmallArgs& a, hipStream_t s);
 int launch_augment_u8(const unsigned char* frames, const cilrs_aug_params* params, int B, int H,
                       int W, float* out_f32, unsigned char* out_u8, hipStream_t s);
+// ---- fp16 inference trunk (infer_f16.hip) -------------------------------------------------------
+typedef _Float16 cilrs_half;
+struct ConvF16Args {
+    const cilrs_half* x;          // [N][H][W][Cin] fp16
+    const cilrs_half* w;          // [Cout][K][K][Cin] fp16, BatchNorm scale folded in
+    const float* bias;            // [Cout] folded BatchNorm shift
+    const cilrs_half* residual;   // [N][Ho][Wo][Cout] or NULL
+    cilrs_half* y;                // [N][Ho][Wo][Cout]
+    int N, H, W, Cin, Ho, Wo, Cout, K, stride, pad, relu;
+};
+struct FoldF16Table {
+    int n;
+    int cout[40];
+    unsigned krow[40];            // K*K*Cin
+    unsigned w[40];               // fp32 weights in the parameter arena
+    unsigned stats[40];           // eval-mode BN stats in the workspace (mean|rstd|scale|shift)
+    unsigned w16[40];             // halfs into the folded-weight arena
+    unsigned bias[40];            // floats into the folded-bias arena
+};
+int launch_conv_f16(const ConvF16Args& a, hipStream_t s);
+int launch_fold_bn_f16(const FoldF16Table& t, const float* params, const float* ws, void* w16,
+                       float* bias, hipStream_t s);
+int launch_f32_to_f16(const float* x, void* y, size_t n, hipStream_t s);
+int launch_avgpool_f16(const void* x, float* out, int N, int HW, int C, int out_ld, hipStream_t s);
+
 // grouped small GEMMs of the heads (heads_gemm.hip): mode 0 NT (linear forward), 1 NN (input
 // gradient), 2 TN (weight + bias gradient); one launch covers up to five chains
 struct HGemmGroup {

@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void heads_small_pre_kernel(
     const int t = threadIdx.x;
     float* out = combined + (size_t)b * 640;
     if (blockIdx.y == 0) {
-        if (t >= 128) return;
+        if (t >= 128 || feat == nullptr) return;     // feat == NULL: already pooled (fp16 trunk)
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
         for (int p = 0; p < HW; ++p)
             s += *reinterpret_cast<const f32x4*>(feat + ((size_t)b * HW + p) * 512 + t * 4);

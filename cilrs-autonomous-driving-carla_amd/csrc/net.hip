@@ -249,6 +249,8 @@ struct cilrs_net {
     int dy_pos = 0;
     int bwd_nblk_next = 0;                 // fused BN-backward partials waiting for their BN
     BnEvalTable bn_table;
+    FoldF16Table f16_table;                // fp16 inference: folded weights / biases / activations
+    size_t f16_w, f16_bias, f16_act[4], f16_act_floats;
     // cached hipGraph of the uint8 inference path (fixed pointers)
     hipGraphExec_t graph_exec = nullptr;
     const void* graph_key[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
@@ -614,6 +616,26 @@ int cilrs_net_create(int batch, int height, int width, cilrs_net** out) {
         n->bn_table.rm[ci] = (unsigned)b.rm; n->bn_table.rv[ci] = (unsigned)b.rv;
         n->bn_table.stats[ci] = (unsigned)n->cg[ci].stats;
     }
+    {   // fp16 inference arenas (every conv but the stem): folded weights, biases, 4 activations
+        size_t halfs = 0, floats = 0;
+        n->f16_table.n = (int)A.convs.size() - 1;
+        for (size_t ci = 1; ci < A.convs.size(); ++ci) {
+            const ConvT& c = A.convs[ci];
+            const int e = (int)ci - 1;
+            n->f16_table.cout[e] = c.cout;
+            n->f16_table.krow[e] = (unsigned)(c.k * c.k * c.cin);
+            n->f16_table.w[e] = (unsigned)c.w;
+            n->f16_table.stats[e] = (unsigned)n->cg[ci].stats;
+            n->f16_table.w16[e] = (unsigned)halfs;
+            n->f16_table.bias[e] = (unsigned)floats;
+            halfs += (size_t)c.cout * c.k * c.k * c.cin;
+            floats += (size_t)c.cout;
+        }
+        n->f16_w = bump.take((halfs + 1) / 2);
+        n->f16_bias = bump.take(floats);
+        n->f16_act_floats = ((size_t)B * n->H1 * n->W1 * 64 + 1) / 2;     // largest trunk tensor
+        for (int k = 0; k < 4; ++k) n->f16_act[k] = bump.take(n->f16_act_floats);
+    }
     n->ws_bytes = bump.off * sizeof(float);
     *out = n;
     return 0;
@@ -635,7 +657,7 @@ size_t cilrs_net_workspace_bytes(const cilrs_net* net) { return net ? net->ws_by
 // ------------------------------------------------------------------------------------------------
 static int forward_from_x4(cilrs_net* net, const cilrs_buffers* bufs, const float* speed,
                            const int64_t* command, int train, float dropout_p, uint64_t seed,
-                           float* controls, float* pred_speed, hipStream_t s) {
+                           float* controls, float* pred_speed, hipStream_t s, int half = 0) {
     const Arch& A = arch();
     float* ws = reinterpret_cast<float*>(bufs->workspace);
     net->ws_base = ws;
@@ -713,6 +735,48 @@ static int forward_from_x4(cilrs_net* net, const cilrs_buffers* bufs, const floa
             launch_maxpool_fwd(ws + net->cg[0].z, ws + net->pool, nullptr, B, net->H0, net->W0,
                                64, s));
         cur = ws + net->pool;
+        if (half) {
+            // ---- fp16 trunk (BASELINE config 5): BatchNorm folded into fp16 weights, fp16 NHWC
+            //      activations, v_mfma_f32_32x32x16_f16 with fp32 accumulation (infer_f16.hip) ----
+            cilrs_half* w16 = reinterpret_cast<cilrs_half*>(ws + net->f16_w);
+            float* b16 = ws + net->f16_bias;
+            cilrs_half* act[4];
+            for (int k = 0; k < 4; ++k) act[k] = reinterpret_cast<cilrs_half*>(ws + net->f16_act[k]);
+            RUN(net, "transform", 0.0, 0.0, s,
+                launch_fold_bn_f16(net->f16_table, P, ws, w16, b16, s));
+            RUN(net, "transform", 0.0, 0.0, s,
+                launch_f32_to_f16(ws + net->pool, act[0], (size_t)B * net->H1 * net->W1 * 64, s));
+            int ic = 0;                                  // index of the buffer holding `cur`
+            auto conv16 = [&](int ci, const cilrs_half* x, const cilrs_half* residual,
+                              cilrs_half* y, int relu) -> int {
+                const ConvT& c = A.convs[ci];
+                const ConvG& g = net->cg[ci];
+                ConvF16Args a;
+                memset(&a, 0, sizeof(a));
+                a.x = x; a.w = w16 + net->f16_table.w16[ci - 1];
+                a.bias = b16 + net->f16_table.bias[ci - 1];
+                a.residual = residual; a.y = y;
+                a.N = B; a.H = g.H; a.W = g.W; a.Cin = c.cin; a.Ho = g.Ho; a.Wo = g.Wo;
+                a.Cout = c.cout; a.K = c.k; a.stride = c.stride; a.pad = c.pad; a.relu = relu;
+                RUN(net, std::string("conv_fwd.") + kGroupName[c.group],
+                    2.0 * g.M * c.cout * c.k * c.k * c.cin, 0.0, s, launch_conv_f16(a, s));
+                return 0;
+            };
+            for (const BlockT& blk : A.blocks) {
+                const int it1 = (ic + 1) & 3, iid = (ic + 2) & 3, io = (ic + 3) & 3;
+                if (conv16(blk.conv1, act[ic], nullptr, act[it1], 1)) return 1;
+                const cilrs_half* identity = act[ic];
+                if (blk.down >= 0) {
+                    if (conv16(blk.down, act[ic], nullptr, act[iid], 0)) return 1;
+                    identity = act[iid];
+                }
+                if (conv16(blk.conv2, act[it1], identity, act[io], 1)) return 1;
+                ic = io;
+            }
+            RUN(net, "heads_fwd", 0.0, 0.0, s,
+                launch_avgpool_f16(act[ic], ws + net->combined, B, net->featHW, 512, 640, s));
+            cur = nullptr;                               // features already pooled into `combined`
+        } else
         for (const BlockT& blk : A.blocks) {
             const ConvT& c1 = A.convs[blk.conv1];
             const ConvT& c2 = A.convs[blk.conv2];
@@ -775,8 +839,9 @@ static int forward_from_x4(cilrs_net* net, const cilrs_buffers* bufs, const floa
     }
 
     // ---- avgpool + flatten -> combined[:, 0:512] ----
-    RUN(net, "heads_fwd", 0.0, 0.0, s,
-        launch_avgpool_fwd(cur, ws + net->combined, B, net->featHW, 512, 640, s));
+    if (cur != nullptr)
+        RUN(net, "heads_fwd", 0.0, 0.0, s,
+            launch_avgpool_fwd(cur, ws + net->combined, B, net->featHW, 512, 640, s));
 
     if (train) {   // backward needs the inputs of the heads
         CILRS_HIP(hipMemcpyAsync(ws + net->speed_in, speed, (size_t)B * sizeof(float),
@@ -885,6 +950,22 @@ int cilrs_net_forward_camera(cilrs_net* net, const cilrs_buffers* bufs, const ui
         launch_camera_to_nhwc4(frames, ws + net->x4, net->B, src_h, src_w, pixel_stride,
                                row_stride, frame_stride, net->H, net->W, mean, stdv, s));
     return forward_from_x4(net, bufs, speed, command, 0, 0.f, 0, controls, pred_speed, s);
+}
+
+int cilrs_net_forward_u8_f16(cilrs_net* net, const cilrs_buffers* bufs, const uint8_t* frames,
+                             const float* speed, const int64_t* command, float* controls,
+                             float* pred_speed, void* stream) {
+    if (check_bufs(net, bufs, false)) return 1;
+    CILRS_CHECK(frames && speed && command && controls && pred_speed,
+                "forward_u8_f16: NULL tensor");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    float* ws = reinterpret_cast<float*>(bufs->workspace);
+    CILRS_HIP(hipMemsetAsync(reinterpret_cast<char*>(bufs->workspace) + net->status_b, 0, 16, s));
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    RUN(net, "transform", 0.0, 0.0, s,
+        launch_u8hwc_to_nhwc4(frames, ws + net->x4, (size_t)net->B * net->H * net->W, mean, stdv,
+                              s));
+    return forward_from_x4(net, bufs, speed, command, 0, 0.f, 0, controls, pred_speed, s, 1);
 }
 
 // Same as cilrs_net_forward_u8, replayed from a cached hipGraph (one launch per frame instead of

@@ -90,6 +90,13 @@ int cilrs_net_forward_camera(cilrs_net* net, const cilrs_buffers* bufs, const ui
                              long frame_stride, const float* speed, const int64_t* command,
                              float* controls, float* pred_speed, void* stream);
 
+/* cilrs_net_forward_u8 with the BasicBlock trunk in fp16 (batched serving, BASELINE config 5):
+ * BatchNorm folded into fp16 weights on every call, fp16 NHWC activations, fp16 MFMA with fp32
+ * accumulation; the stem and the heads stay fp32.  Outputs agree with the fp32 path to ~1e-3. */
+int cilrs_net_forward_u8_f16(cilrs_net* net, const cilrs_buffers* bufs, const uint8_t* frames,
+                             const float* speed, const int64_t* command, float* controls,
+                             float* pred_speed, void* stream);
+
 /* cilrs_net_forward_u8 replayed from a cached hipGraph (re-captured when a pointer changes);
  * `stream` must be a non-default stream.  Single-frame control loop: predict_controls,
  * autonomous_drive.py:908-920. */
