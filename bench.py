@@ -273,6 +273,20 @@ def main():
         out["infer_batch64_f16"] = {"frames_per_s": round(64 / dt, 1),
                                     "ms_per_batch": round(dt * 1e3, 3), "dtype": "f16 trunk",
                                     "frames": 320}
+        # ... and replayed from a hipGraph on a side stream (BASELINE config 5 as stated)
+        gs = torch.cuda.Stream(device=dev)
+        oc, osp = torch.empty(64, 3, device=dev), torch.empty(64, device=dev)
+        with torch.cuda.stream(gs):
+            for _ in range(3):
+                trainer.eng.run_forward_u8(u64[0], spd64, cmd64, out=(oc, osp), graph=True, half=True)
+            gs.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(20):
+                trainer.eng.run_forward_u8(u64[0], spd64, cmd64, out=(oc, osp), graph=True, half=True)
+            gs.synchronize()
+        dt = (time.perf_counter() - t1) / 20
+        out["infer_batch64_f16"]["graph_ms_per_batch"] = round(dt * 1e3, 3)
+        out["infer_batch64_f16"]["graph_frames_per_s"] = round(64 / dt, 1)
         # device-side breakdown of one B=1 forward (eager launches, hipEvent per kernel)
         pl1 = trainer.eng.plan(1, 88, 200)
         pl1.profile_reset()

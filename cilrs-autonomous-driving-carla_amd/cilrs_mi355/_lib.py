@@ -49,6 +49,7 @@ SIGNATURES = {
     "cilrs_net_forward_camera": (i32, [vp, C.POINTER(Buffers), vp, i32, i32, i32, C.c_long,
                                        C.c_long, vp, vp, vp, vp, vp]),
     "cilrs_net_forward_u8_f16": (i32, [vp, C.POINTER(Buffers), vp, vp, vp, vp, vp, vp]),
+    "cilrs_net_forward_u8_f16_graph": (i32, [vp, C.POINTER(Buffers), vp, vp, vp, vp, vp, vp]),
     "cilrs_net_forward_u8_graph": (i32, [vp, C.POINTER(Buffers), vp, vp, vp, vp, vp, vp]),
     "cilrs_loss_fwd_bwd": (i32, [vp, vp, vp, vp, i32, i32, c_float_p, f32, vp, vp, vp, vp]),
     "cilrs_net_backward": (i32, [vp, C.POINTER(Buffers), vp, vp, i32, i32, vp]),

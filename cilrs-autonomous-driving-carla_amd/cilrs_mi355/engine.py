@@ -229,10 +229,10 @@ class Engine:
             pred_speed = torch.empty(b, dtype=torch.float32, device=self.device)
         else:
             controls, pred_speed = out
-        if half and graph:
-            raise RuntimeError("run_forward_u8: half=True is an eager path")
-        fn = (L.lib().cilrs_net_forward_u8_f16 if half else
-              L.lib().cilrs_net_forward_u8_graph if graph else L.lib().cilrs_net_forward_u8)
+        lib = L.lib()
+        fn = ((lib.cilrs_net_forward_u8_f16_graph if graph else lib.cilrs_net_forward_u8_f16)
+              if half else
+              (lib.cilrs_net_forward_u8_graph if graph else lib.cilrs_net_forward_u8))
         L.check(fn(pl.handle, C.byref(self.bufs[(pl.batch, pl.h, pl.w)]), L.ptr(frames_u8),
                    L.ptr(speed.contiguous()), L.ptr(command.contiguous()), L.ptr(controls),
                    L.ptr(pred_speed), self._stream()))

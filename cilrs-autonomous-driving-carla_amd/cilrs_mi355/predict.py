@@ -26,12 +26,14 @@ class Predictor:
     (0.69 vs 0.76 ms device time at B=1: the path is bound by ~75 dependent small kernels, not by
     host launch overhead), so it is off by default."""
 
-    def __init__(self, model, batch=1, height=IMG_HEIGHT, width=IMG_WIDTH, use_graph=False):
+    def __init__(self, model, batch=1, height=IMG_HEIGHT, width=IMG_WIDTH, use_graph=False,
+                 half=False):
         self.model = model.eval()
         self.eng = model.engine()
         dev = self.eng.device
         self.batch = batch
         self.use_graph = use_graph
+        self.half = half              # fp16 BasicBlock trunk (batched serving, BASELINE config 5)
         self.stream = torch.cuda.Stream(device=dev)      # hipGraph capture needs its own stream
         self.ctrl_dev = torch.empty(batch, 3, dtype=torch.float32, device=dev)
         self.spd_out_dev = torch.empty(batch, dtype=torch.float32, device=dev)
@@ -55,7 +57,7 @@ class Predictor:
         (steer, throttle, brake, speed_kmh)."""
         if self.model.engine() is not self.eng:
             self.__init__(self.model, self.batch, self.frames_host.size(1),
-                          self.frames_host.size(2), self.use_graph)
+                          self.frames_host.size(2), self.use_graph, self.half)
         if self.model.training:
             self.model.eval()
         # host staging through NUMPY views of the pinned buffers: torch CPU ops would wake the
@@ -71,7 +73,8 @@ class Predictor:
             self.speed_dev.copy_(self.speed_host, non_blocking=True)
             self.cmd_dev.copy_(self.cmd_host, non_blocking=True)
             self.eng.run_forward_u8(self.frames_dev, self.speed_dev, self.cmd_dev,
-                                    out=(self.ctrl_dev, self.spd_out_dev), graph=self.use_graph)
+                                    out=(self.ctrl_dev, self.spd_out_dev), graph=self.use_graph,
+                                    half=self.half)
             # two tiny D2H copies into pinned memory; no torch kernels, no allocations
             self.ctrl_host.copy_(self.ctrl_dev, non_blocking=True)
             self.spd_out_host.copy_(self.spd_out_dev, non_blocking=True)
@@ -92,7 +95,7 @@ class Predictor:
             raise RuntimeError("camera frame must be uint8 [Hs,Ws,3 or 4]")
         if self.model.engine() is not self.eng:
             self.__init__(self.model, self.batch, self.frames_host.size(1),
-                          self.frames_host.size(2), self.use_graph)
+                          self.frames_host.size(2), self.use_graph, self.half)
         if self.model.training:
             self.model.eval()
         cam = getattr(self, "_cam", None)

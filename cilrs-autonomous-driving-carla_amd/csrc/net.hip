@@ -253,6 +253,7 @@ struct cilrs_net {
     size_t f16_w, f16_bias, f16_act[4], f16_act_floats;
     // cached hipGraph of the uint8 inference path (fixed pointers)
     hipGraphExec_t graph_exec = nullptr;
+    int graph_half = 0;
     const void* graph_key[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                                 nullptr};
     bool warmed = false;
@@ -971,21 +972,21 @@ int cilrs_net_forward_u8_f16(cilrs_net* net, const cilrs_buffers* bufs, const ui
 // Same as cilrs_net_forward_u8, replayed from a cached hipGraph (one launch per frame instead of
 // ~80): the B=1 control-loop path (autonomous_drive.py:908-920) is launch-latency bound.  The
 // graph is re-captured when any pointer changes.  `stream` must not be the legacy NULL stream.
-int cilrs_net_forward_u8_graph(cilrs_net* net, const cilrs_buffers* bufs, const uint8_t* frames,
-                               const float* speed, const int64_t* command, float* controls,
-                               float* pred_speed, void* stream) {
+static int forward_u8_graph(cilrs_net* net, const cilrs_buffers* bufs, const uint8_t* frames,
+                            const float* speed, const int64_t* command, float* controls,
+                            float* pred_speed, void* stream, int half) {
+    auto eager = half ? cilrs_net_forward_u8_f16 : cilrs_net_forward_u8;
     if (check_bufs(net, bufs, false)) return 1;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     CILRS_CHECK(s != nullptr, "forward_u8_graph: capture needs a non-default stream");
     const void* key[8] = {bufs->params, bufs->bn_running, bufs->workspace, frames, speed, command,
                           controls, pred_speed};
-    bool same = net->graph_exec != nullptr;
+    bool same = net->graph_exec != nullptr && net->graph_half == half;
     for (int i = 0; i < 8 && same; ++i) same = key[i] == net->graph_key[i];
     if (!same) {
         if (!net->warmed) {      // first call eager: function attributes, side streams, events
             if (ensure_streams(net)) return 1;
-            if (cilrs_net_forward_u8(net, bufs, frames, speed, command, controls, pred_speed,
-                                     stream)) return 1;
+            if (eager(net, bufs, frames, speed, command, controls, pred_speed, stream)) return 1;
             CILRS_HIP(hipStreamSynchronize(s));
             net->warmed = true;
         }
@@ -993,8 +994,7 @@ int cilrs_net_forward_u8_graph(cilrs_net* net, const cilrs_buffers* bufs, const 
         net->prof.on = false;
         hipGraph_t graph = nullptr;
         CILRS_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-        const int rc = cilrs_net_forward_u8(net, bufs, frames, speed, command, controls,
-                                            pred_speed, stream);
+        const int rc = eager(net, bufs, frames, speed, command, controls, pred_speed, stream);
         const hipError_t e = hipStreamEndCapture(s, &graph);
         net->prof.on = prof;
         CILRS_CHECK(rc == 0, "forward_u8_graph: capture failed: %s", last_error());
@@ -1005,9 +1005,23 @@ int cilrs_net_forward_u8_graph(cilrs_net* net, const cilrs_buffers* bufs, const 
         (void)hipGraphDestroy(graph);
         CILRS_CHECK(e2 == hipSuccess, "hipGraphInstantiate failed: %s", hipGetErrorString(e2));
         for (int i = 0; i < 8; ++i) net->graph_key[i] = key[i];
+        net->graph_half = half;
     }
     CILRS_HIP(hipGraphLaunch(net->graph_exec, s));
     return 0;
+}
+
+int cilrs_net_forward_u8_graph(cilrs_net* net, const cilrs_buffers* bufs, const uint8_t* frames,
+                               const float* speed, const int64_t* command, float* controls,
+                               float* pred_speed, void* stream) {
+    return forward_u8_graph(net, bufs, frames, speed, command, controls, pred_speed, stream, 0);
+}
+
+int cilrs_net_forward_u8_f16_graph(cilrs_net* net, const cilrs_buffers* bufs,
+                                   const uint8_t* frames, const float* speed,
+                                   const int64_t* command, float* controls, float* pred_speed,
+                                   void* stream) {
+    return forward_u8_graph(net, bufs, frames, speed, command, controls, pred_speed, stream, 1);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -96,6 +96,12 @@ int cilrs_net_forward_camera(cilrs_net* net, const cilrs_buffers* bufs, const ui
 int cilrs_net_forward_u8_f16(cilrs_net* net, const cilrs_buffers* bufs, const uint8_t* frames,
                              const float* speed, const int64_t* command, float* controls,
                              float* pred_speed, void* stream);
+/* ... replayed from a cached hipGraph (same rules as cilrs_net_forward_u8_graph; one cached graph
+ * per plan, re-captured when the mode or a pointer changes). */
+int cilrs_net_forward_u8_f16_graph(cilrs_net* net, const cilrs_buffers* bufs,
+                                   const uint8_t* frames, const float* speed,
+                                   const int64_t* command, float* controls, float* pred_speed,
+                                   void* stream);
 
 /* cilrs_net_forward_u8 replayed from a cached hipGraph (re-captured when a pointer changes);
  * `stream` must be a non-default stream.  Single-frame control loop: predict_controls,

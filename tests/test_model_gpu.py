@@ -524,3 +524,10 @@ def test_fp16_trunk_inference_matches_fp32(B):
     c16b, _ = eng.run_forward_u8(frames, spd.cuda(), cmd.cuda(), half=True)
     c32b, _ = eng.run_forward_u8(frames, spd.cuda(), cmd.cuda())
     assert torch.equal(c16, c16b) and torch.equal(c32, c32b)
+    # hipGraph replay of the fp16 forward (the serving configuration) == the eager launches
+    from cilrs_mi355.predict import Predictor
+    pr = Predictor(m, batch=B, use_graph=True, half=True)
+    kmh = (spd.numpy().astype(np.float64) * 90.0).tolist()
+    for _ in range(3):
+        got = pr.predict_batch(u8, kmh, cmd.numpy())
+    assert np.abs(got[:, :3] - c16.cpu().numpy()).max() <= 1e-6
