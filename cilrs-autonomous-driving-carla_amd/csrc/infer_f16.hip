@@ -163,10 +163,14 @@ __global__ __launch_bounds__(256) void fold_bn_f16_kernel(const FoldF16Table t,
     const int C = t.cout[l];
     const size_t krow = t.krow[l], n = (size_t)C * krow;
     half_t* dst = w16 + t.w16[l];
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (size_t)gridDim.x * blockDim.x) {
-        const int o = (int)(i / krow);
-        dst[i] = (half_t)(w[i] * stats[2 * C + o]);
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    for (size_t i4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i4 < n / 4;     // krow % 4 == 0
+         i4 += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = i4 * 4;
+        const float sc = stats[2 * C + (int)(i / krow)];
+        const f32x4 v = *reinterpret_cast<const f32x4*>(w + i);
+        h4 o = {(half_t)(v[0] * sc), (half_t)(v[1] * sc), (half_t)(v[2] * sc), (half_t)(v[3] * sc)};
+        *reinterpret_cast<h4*>(dst + i) = o;
     }
     if (blockIdx.x == 0)
         for (int o = threadIdx.x; o < C; o += blockDim.x) bias[t.bias[l] + o] = stats[3 * C + o];
@@ -176,9 +180,10 @@ __global__ __launch_bounds__(256) void f32_to_f16_kernel(const float* __restrict
                                                          half_t* __restrict__ y, const size_t n4) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
          i += (size_t)gridDim.x * blockDim.x) {
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
         const f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
-        half_t* o = y + i * 4;
-        o[0] = (half_t)v[0]; o[1] = (half_t)v[1]; o[2] = (half_t)v[2]; o[3] = (half_t)v[3];
+        h4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+        *reinterpret_cast<h4*>(y + i * 4) = o;
     }
 }
 
@@ -209,7 +214,7 @@ int launch_conv_f16(const ConvF16Args& a, hipStream_t s) {
 
 int launch_fold_bn_f16(const FoldF16Table& t, const float* params, const float* ws, void* w16,
                        float* bias, hipStream_t s) {
-    fold_bn_f16_kernel<<<dim3(64, t.n), 256, 0, s>>>(t, params, ws, reinterpret_cast<half_t*>(w16),
+    fold_bn_f16_kernel<<<dim3(128, t.n), 256, 0, s>>>(t, params, ws, reinterpret_cast<half_t*>(w16),
                                                      bias);
     CILRS_LAUNCH_CHECK();
     return 0;
