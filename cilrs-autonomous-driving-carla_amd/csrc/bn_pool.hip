@@ -346,6 +346,168 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
     }
 }
 
+// ---- stem: BatchNorm apply + ReLU + MaxPool in one pass, and its backward ------------------------
+// The stem's post-BN tensor z (144 MB at B=128) is never materialised: the forward pools
+// relu(y*w + b) straight from the conv output y, and the backward rebuilds both the max-pool
+// gradient (gather over the <= 4 windows that selected a pixel) and the ReLU mask (y*w + b > 0)
+// on the fly.  Saves one write and three reads of z, the write + two reads of dz, and a launch.
+__device__ __forceinline__ f32x4 bn_relu4(const f32x4 v, const f32x4 w, const f32x4 b) {
+    f32x4 r = v * w + b;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = fmaxf(r[e], 0.f);
+    return r;
+}
+
+__global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(
+    const float* __restrict__ y, const float* __restrict__ stats, float* __restrict__ out,
+    unsigned char* __restrict__ argmax, const int N, const int H, const int W, const int C,
+    const int Ho, const int Wo) {
+    const int cq = C >> 2;
+    const size_t total = (size_t)N * Ho * Wo * cq;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i % cq);
+        size_t p = i / cq;
+        const int ow = (int)(p % Wo); p /= Wo;
+        const int oh = (int)(p % Ho);
+        const int n = (int)(p / Ho);
+        const f32x4 sw = *reinterpret_cast<const f32x4*>(stats + 2 * C + q * 4);
+        const f32x4 sb = *reinterpret_cast<const f32x4*>(stats + 3 * C + q * 4);
+        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int bi[4] = {0, 0, 0, 0};
+        bool first = true;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int h = oh * 2 - 1 + kh;
+            if (h < 0 || h >= H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int w = ow * 2 - 1 + kw;
+                if (w < 0 || w >= W) continue;
+                const f32x4 v = bn_relu4(
+                    *reinterpret_cast<const f32x4*>(y + ((size_t)(n * H + h) * W + w) * C + q * 4),
+                    sw, sb);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (first || v[e] > best[e] || v[e] != v[e]) {
+                        best[e] = v[e];
+                        bi[e] = kh * 3 + kw;
+                    }
+                }
+                first = false;
+            }
+        }
+        *reinterpret_cast<f32x4*>(out + i * 4) = best;
+        uchar4 a;
+        a.x = (unsigned char)bi[0]; a.y = (unsigned char)bi[1];
+        a.z = (unsigned char)bi[2]; a.w = (unsigned char)bi[3];
+        *reinterpret_cast<uchar4*>(argmax + i * 4) = a;
+    }
+}
+
+// g(n,h,w,c) = [y*w+b > 0] * sum over the pooling windows that selected (h,w) of dpool
+__device__ __forceinline__ f32x4 pool_relu_grad(const float* __restrict__ dpool,
+                                                const unsigned char* __restrict__ argmax,
+                                                const f32x4 yv, const f32x4 sw, const f32x4 sb,
+                                                const int n, const int h, const int w, const int q,
+                                                const int cq, const int Ho, const int Wo) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int kh = 0; kh < 3; ++kh) {
+        const int t = h + 1 - kh;
+        if (t < 0 || (t & 1)) continue;
+        const int oh = t >> 1;
+        if (oh >= Ho) continue;
+        for (int kw = 0; kw < 3; ++kw) {
+            const int u = w + 1 - kw;
+            if (u < 0 || (u & 1)) continue;
+            const int ow = u >> 1;
+            if (ow >= Wo) continue;
+            const size_t o = (((size_t)(n * Ho + oh) * Wo + ow) * cq + q) * 4;
+            const uchar4 a = *reinterpret_cast<const uchar4*>(argmax + o);
+            const f32x4 g = *reinterpret_cast<const f32x4*>(dpool + o);
+            const int k = kh * 3 + kw;
+            if (a.x == k) acc[0] += g[0];
+            if (a.y == k) acc[1] += g[1];
+            if (a.z == k) acc[2] += g[2];
+            if (a.w == k) acc[3] += g[3];
+        }
+    }
+    const f32x4 z = yv * sw + sb;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = z[e] > 0.f ? acc[e] : 0.f;
+    return acc;
+}
+
+// column partials of the stem's BatchNorm backward (layout of bn_colreduce_kernel<1>)
+__global__ __launch_bounds__(256) void bn_colreduce_pool_kernel(
+    const float* __restrict__ y, const float* __restrict__ dpool,
+    const unsigned char* __restrict__ argmax, const float* __restrict__ stats,
+    float* __restrict__ partial, const int N, const int H, const int W, const int C, const int Ho,
+    const int Wo, const int rows_per_block) {
+    __shared__ float red[2][256 * 4];
+    const int M = N * H * W;
+    const int cq = C >> 2, tpr = cq, rpi = 256 / tpr;
+    const int q = threadIdx.x % tpr, rsub = threadIdx.x / tpr;
+    const int row_begin = blockIdx.x * rows_per_block;
+    const int row_end = min(M, row_begin + rows_per_block);
+    const f32x4 mean = *reinterpret_cast<const f32x4*>(stats + q * 4);
+    const f32x4 rstd = *reinterpret_cast<const f32x4*>(stats + C + q * 4);
+    const f32x4 sw = *reinterpret_cast<const f32x4*>(stats + 2 * C + q * 4);
+    const f32x4 sb = *reinterpret_cast<const f32x4*>(stats + 3 * C + q * 4);
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    for (int r = row_begin + rsub; r < row_end; r += rpi) {
+        const int w = r % W, t = r / W, h = t % H, n = t / H;
+        const f32x4 yv = *reinterpret_cast<const f32x4*>(y + (size_t)r * C + q * 4);
+        const f32x4 g = pool_relu_grad(dpool, argmax, yv, sw, sb, n, h, w, q, cq, Ho, Wo);
+        s1 += g;
+        s2 += g * ((yv - mean) * rstd);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        red[0][threadIdx.x * 4 + e] = s1[e];
+        red[1][threadIdx.x * 4 + e] = s2[e];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float a1 = 0.f, a2 = 0.f;
+        const int qq = c >> 2, e = c & 3;
+        for (int rs = 0; rs < rpi; ++rs) {
+            a1 += red[0][(rs * tpr + qq) * 4 + e];
+            a2 += red[1][(rs * tpr + qq) * 4 + e];
+        }
+        partial[(size_t)c * gridDim.x + blockIdx.x] = a1;
+        partial[(size_t)(C + c) * gridDim.x + blockIdx.x] = a2;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_pool_kernel(
+    const float* __restrict__ y, const float* __restrict__ dpool,
+    const unsigned char* __restrict__ argmax, const float* __restrict__ stats,
+    const float* __restrict__ coef, float* __restrict__ dy, const int N, const int H, const int W,
+    const int C, const int Ho, const int Wo) {
+    const int cq = C >> 2;
+    const size_t total4 = (size_t)N * H * W * cq;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i % cq);
+        size_t p = i / cq;
+        const int w = (int)(p % W); p /= W;
+        const int h = (int)(p % H);
+        const int n = (int)(p / H);
+        const f32x4 mean = *reinterpret_cast<const f32x4*>(stats + q * 4);
+        const f32x4 rstd = *reinterpret_cast<const f32x4*>(stats + C + q * 4);
+        const f32x4 sw = *reinterpret_cast<const f32x4*>(stats + 2 * C + q * 4);
+        const f32x4 sb = *reinterpret_cast<const f32x4*>(stats + 3 * C + q * 4);
+        const f32x4 c1 = *reinterpret_cast<const f32x4*>(coef + q * 4);
+        const f32x4 c2 = *reinterpret_cast<const f32x4*>(coef + C + q * 4);
+        const f32x4 c3 = *reinterpret_cast<const f32x4*>(coef + 2 * C + q * 4);
+        const f32x4 yv = *reinterpret_cast<const f32x4*>(y + i * 4);
+        const f32x4 g = pool_relu_grad(dpool, argmax, yv, sw, sb, n, h, w, q, cq, Ho, Wo);
+        const f32x4 xh = (yv - mean) * rstd;
+        *reinterpret_cast<f32x4*>(dy + i * 4) = (g - c2 - xh * c3) * c1;
+    }
+}
+
 // ---- AdaptiveAvgPool2d((1,1)) + Flatten ------------------------------------------------------
 __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const float* __restrict__ x,
                                                           float* __restrict__ out, const int N,
@@ -472,6 +634,38 @@ int launch_bn_bwd(const float* dz, const float* z, const float* y, int M, int C,
     const size_t total4 = (size_t)M * C / 4;
     bn_bwd_apply_kernel<<<grid_for(total4), 256, 0, s>>>(dz, z, y, stats, coef, dy, g_out, total4,
                                                          C, relu);
+    CILRS_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_bn_relu_maxpool_fwd(const float* y, const float* stats, float* out,
+                               unsigned char* argmax, int N, int H, int W, int C, hipStream_t s) {
+    CILRS_CHECK(C % 4 == 0 && argmax != nullptr, "bn_relu_maxpool: C %% 4, argmax required");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const size_t total = (size_t)N * Ho * Wo * (C / 4);
+    bn_relu_maxpool_fwd_kernel<<<grid_for(total), 256, 0, s>>>(y, stats, out, argmax, N, H, W, C,
+                                                               Ho, Wo);
+    CILRS_LAUNCH_CHECK();
+    return 0;
+}
+
+// BatchNorm backward of  maxpool(relu(bn(y)))  given d(maxpool output): dgamma, dbeta, dy
+int launch_bn_bwd_pool(const float* dpool, const unsigned char* argmax, const float* y, int N,
+                       int H, int W, int C, const float* gamma, const float* stats, float* dgamma,
+                       float* dbeta, float* coef, float* partial, float* dy, hipStream_t s) {
+    if (check_c(C)) return 1;
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const int M = N * H * W;
+    const ColPlan p = col_plan(M, C);
+    bn_colreduce_pool_kernel<<<p.nblk, 256, 0, s>>>(y, dpool, argmax, stats, partial, N, H, W, C,
+                                                    Ho, Wo, p.rows_per_block);
+    CILRS_LAUNCH_CHECK();
+    bn_bwd_finalize_kernel<<<cdiv(C, kFinChannels), 64 * kFinChannels, 0, s>>>(
+        partial, p.nblk, M, C, gamma, stats, dgamma, dbeta, coef, 0);
+    CILRS_LAUNCH_CHECK();
+    const size_t total4 = (size_t)M * C / 4;
+    bn_bwd_apply_pool_kernel<<<grid_for(total4), 256, 0, s>>>(y, dpool, argmax, stats, coef, dy, N,
+                                                             H, W, C, Ho, Wo);
     CILRS_LAUNCH_CHECK();
     return 0;
 }

@@ -155,6 +155,12 @@ int launch_bn_bwd(const float* dz, const float* z, const float* y, int M, int C,
                   const float* gamma, const float* stats, int relu, float* dgamma, float* dbeta,
                   int accumulate, float* coef, float* partial, float* dy, float* g_out,
                   int pre_nblk, hipStream_t s);
+// stem: BatchNorm apply + ReLU + max-pool without materialising the post-BN tensor, and its backward
+int launch_bn_relu_maxpool_fwd(const float* y, const float* stats, float* out,
+                               unsigned char* argmax, int N, int H, int W, int C, hipStream_t s);
+int launch_bn_bwd_pool(const float* dpool, const unsigned char* argmax, const float* y, int N,
+                       int H, int W, int C, const float* gamma, const float* stats, float* dgamma,
+                       float* dbeta, float* coef, float* partial, float* dy, hipStream_t s);
 int launch_maxpool_fwd(const float* x, float* out, unsigned char* argmax, int N, int H, int W,
                        int C, hipStream_t s);
 int launch_maxpool_bwd(const float* dout, const unsigned char* argmax, float* dx, int N, int H,

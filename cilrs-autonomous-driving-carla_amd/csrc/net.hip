@@ -695,11 +695,23 @@ static int forward_from_x4(cilrs_net* net, const cilrs_buffers* bufs, const floa
         int nb = 0;                             // batch statistics fused into the conv epilogue
         if (conv_fwd(net, A.convs[0], net->cg[0], ws + net->x4, 4, ws + net->w4,
                      ws + net->cg[0].y, ws, s, &nb)) return 1;
-        if (bn(0, nullptr, 1, nb)) return 1;
+        // stem BatchNorm: statistics only -- its apply + ReLU is fused into the max-pool, the
+        // post-BN tensor (144 MB at B=128) is never written
+        {
+            const ConvT& c0 = A.convs[0];
+            const ConvG& g0 = net->cg[0];
+            const BnT& b0 = A.bns[c0.bn];
+            RUN(net, "bn_fwd.stem", 0.0, 0.0, s,
+                launch_bn_train_fwd(ws + g0.y, g0.M, c0.cout, P + b0.gamma, P + b0.beta,
+                                    R + b0.rm, R + b0.rv,
+                                    reinterpret_cast<long long*>(bufs->bn_nbt) + c0.bn, mom, eps,
+                                    nullptr, 1, ws + g0.stats, ws + net->bn_partial, nullptr, nb,
+                                    s));
+        }
         unsigned char* argmax = reinterpret_cast<unsigned char*>(bufs->workspace) + net->argmax_b;
         RUN(net, "maxpool", 0.0, 4.0 * net->cg[0].M * 64 * 1.25, s,
-            launch_maxpool_fwd(ws + net->cg[0].z, ws + net->pool, argmax, B, net->H0, net->W0,
-                               64, s));
+            launch_bn_relu_maxpool_fwd(ws + net->cg[0].y, ws + net->cg[0].stats, ws + net->pool,
+                                       argmax, B, net->H0, net->W0, 64, s));
         // ---- BasicBlocks ----
         cur = ws + net->pool;
         for (const BlockT& blk : A.blocks) {
@@ -1148,13 +1160,11 @@ int cilrs_net_backward(cilrs_net* net, const cilrs_buffers* bufs, const float* d
             const BnT& b0 = A.bns[c0.bn];
             const unsigned char* argmax =
                 reinterpret_cast<const unsigned char*>(bufs->workspace) + net->argmax_b;
-            RUN(net, "maxpool", 0.0, 4.0 * g0.M * 64 * 1.5, s,
-                launch_maxpool_bwd(ws + net->G[3], argmax, ws + net->G[0], B, net->H0, net->W0,
-                                   64, s));
-            RUN(net, "bn_bwd.stem", 0.0, 4.0 * g0.M * 64 * 7.0, s,
-                launch_bn_bwd(ws + net->G[0], ws + g0.z, ws + g0.y, g0.M, 64, P + b0.gamma,
-                              ws + g0.stats, 1, Gp + b0.gamma, Gp + b0.beta, 0, ws + net->bn_coef,
-                              ws + net->bn_partial, ws + net->G[1], nullptr, 0, s));
+            // max-pool backward + ReLU mask are rebuilt inside the BatchNorm-backward passes
+            RUN(net, "bn_bwd.stem", 0.0, 4.0 * g0.M * 64 * 3.0, s,
+                launch_bn_bwd_pool(ws + net->G[3], argmax, ws + g0.y, B, net->H0, net->W0, 64,
+                                   P + b0.gamma, ws + g0.stats, Gp + b0.gamma, Gp + b0.beta,
+                                   ws + net->bn_coef, ws + net->bn_partial, ws + net->G[1], s));
             if (conv_wgrad(net, c0, g0, ws + net->x4, 4, ws + net->G[1], Gp + c0.w, ws, s))
                 return 1;
         }
