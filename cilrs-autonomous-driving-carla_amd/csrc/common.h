@@ -215,6 +215,21 @@ int launch_heads_small_pre(const float* feat, int HW, const float* speed, const 
 int launch_heads_small_layer(const HeadsSmallArgs& a, hipStream_t s);
 int launch_augment_u8(const unsigned char* frames, const cilrs_aug_params* params, int B, int H,
                       int W, float* out_f32, unsigned char* out_u8, hipStream_t s);
+// ---- single-frame inference convolution (conv_small.hip) --------------------------------------
+struct ConvSmallArgs {
+    const float* x; const float* w; float* y;      // NHWC / OHWI / NHWC, dense
+    const float* scale; const float* shift;        // folded eval-mode BatchNorm per output channel
+    const float* addend;                           // residual, layout of y (may be NULL)
+    int relu, relu_post;
+    int N, H, W, Cin, Ho, Wo, Cout, K, stride, pad;
+};
+int launch_conv_small(const ConvSmallArgs& a, hipStream_t s);
+// measured (tools/f16_probe.py): at B=1 it beats split-K + reduce on layers 2-3 (144 / 80 tiles,
+// reduction length <= 2304) and loses on layer1 (276 tiles: mostly idle 16-wave blocks), on layer4
+// (reduction length 4608: two dependent rounds of loads per wave) and on layer3 at B=4 (320 tiles)
+constexpr int kSmallConvBlocks = 256;              // 16x16 tiles up to which it is used
+constexpr int kSmallConvK = 2304;                  // reduction length up to which it is used
+
 // ---- fp16 inference trunk (infer_f16.hip) -------------------------------------------------------
 typedef _Float16 cilrs_half;
 struct ConvF16Args {

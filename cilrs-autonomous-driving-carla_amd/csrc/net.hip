@@ -789,25 +789,43 @@ static int forward_from_x4(cilrs_net* net, const cilrs_buffers* bufs, const floa
             RUN(net, "heads_fwd", 0.0, 0.0, s,
                 launch_avgpool_f16(act[ic], ws + net->combined, B, net->featHW, 512, 640, s));
             cur = nullptr;                               // features already pooled into `combined`
-        } else
+        } else {
+        // a layer with few output pixels (single-frame inference) takes the one-launch
+        // latency kernel (conv_small.hip) instead of split-K implicit GEMM + reduce
+        auto conv_eval = [&](const ConvT& c, const ConvG& g, const float* x, float* y, int relu,
+                             const float* addend, int relu_post) -> int {
+            // one 16-wave block per 16x16 tile: worth it while every block gets its own CU
+            if (cdiv(g.M, 16) * (c.cout / 16) > kSmallConvBlocks || c.cin % 16 != 0 ||
+                c.k * c.k * c.cin > kSmallConvK)
+                return conv_fwd(net, c, g, x, c.cin, P + c.w, y, ws, s, nullptr, ws + g.stats,
+                                relu, addend, relu_post);
+            ConvSmallArgs a;
+            memset(&a, 0, sizeof(a));
+            a.x = x; a.w = P + c.w; a.y = y;
+            a.scale = ws + g.stats + 2 * c.cout; a.shift = ws + g.stats + 3 * c.cout;
+            a.addend = addend; a.relu = relu; a.relu_post = relu_post;
+            a.N = B; a.H = g.H; a.W = g.W; a.Cin = c.cin; a.Ho = g.Ho; a.Wo = g.Wo;
+            a.Cout = c.cout; a.K = c.k; a.stride = c.stride; a.pad = c.pad;
+            RUN(net, std::string("conv_fwd.") + kGroupName[c.group],
+                2.0 * g.M * c.cout * c.k * c.k * c.cin, 0.0, s, launch_conv_small(a, s));
+            return 0;
+        };
         for (const BlockT& blk : A.blocks) {
             const ConvT& c1 = A.convs[blk.conv1];
             const ConvT& c2 = A.convs[blk.conv2];
             const ConvG& g1 = net->cg[blk.conv1];
             const ConvG& g2 = net->cg[blk.conv2];
-            if (conv_fwd(net, c1, g1, cur, c1.cin, P + c1.w, ws + g1.z, ws, s, nullptr,
-                         ws + g1.stats, 1)) return 1;
+            if (conv_eval(c1, g1, cur, ws + g1.z, 1, nullptr, 0)) return 1;
             const float* identity = cur;
             if (blk.down >= 0) {
                 const ConvT& cd = A.convs[blk.down];
                 const ConvG& gd = net->cg[blk.down];
-                if (conv_fwd(net, cd, gd, cur, cd.cin, P + cd.w, ws + gd.z, ws, s, nullptr,
-                             ws + gd.stats, 0)) return 1;
+                if (conv_eval(cd, gd, cur, ws + gd.z, 0, nullptr, 0)) return 1;
                 identity = ws + gd.z;
             }
-            if (conv_fwd(net, c2, g2, ws + g1.z, c2.cin, P + c2.w, ws + g2.z, ws, s, nullptr,
-                         ws + g2.stats, 0, identity, 1)) return 1;
+            if (conv_eval(c2, g2, ws + g1.z, ws + g2.z, 0, identity, 1)) return 1;
             cur = ws + g2.z;
+        }
         }
     }
 
