@@ -47,15 +47,24 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // bank conflicts are avoided by XOR-swizzling the 16-B chunk index with (row>>1)&7 on the SOURCE
 // address and on the ds_read side (synthetic ladder tools/mfma_probe.hip: 104 vs 70 TF at one
 // block/CU, 123 vs 110 at three).
+// The register-staged 64x64 tile also uses the unpadded, XOR-swizzled LDS image: 32 KB per block
+// instead of 36.9 KB lets FIVE blocks share a CU (160 KB LDS, <= 96 VGPRs), i.e. 1,280 block slots
+// instead of 1,024 -- layer2's 1,100 tiles then fit in one round.
+template <int BM, int BN, bool TAP_UNIFORM, bool DMA>
+constexpr bool igemm_swz() { return DMA || (BM == 64 && BN == 64 && TAP_UNIFORM); }
+template <int BM, int BN, bool TAP_UNIFORM, bool DMA>
+constexpr int igemm_min_blocks() { return (!DMA && BM == 64 && BN == 64 && TAP_UNIFORM) ? 5 : 2; }
+
 template <int BM, int BN, int WM, int WN, bool TAP_UNIFORM, int W_MODE, bool DMA>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a, const int M,
-                                                         const int Krow, const int KT) {
+__global__ __launch_bounds__(256, (igemm_min_blocks<BM, BN, TAP_UNIFORM, DMA>()))
+void conv_igemm_kernel(const ConvArgs a, const int M, const int Krow, const int KT) {
     static_assert(WM * WN == 4, "4 waves");
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
     constexpr int A_PASSES = BM / 32, B_PASSES = BN / 32;
-    constexpr int APIT = DMA ? BK : APITCH;                       // A (and k-contiguous B) pitch
-    constexpr int BPITCH1 = DMA ? BN : BN + 4;                    // W_MODE 1 (k-major B) pitch
+    constexpr bool SWZ = igemm_swz<BM, BN, TAP_UNIFORM, DMA>();
+    constexpr int APIT = SWZ ? BK : APITCH;                       // A (and k-contiguous B) pitch
+    constexpr int BPITCH1 = SWZ ? BN : BN + 4;                    // W_MODE 1 (k-major B) pitch
     constexpr int B_FLOATS = (W_MODE == 0) ? BN * APIT : BK * BPITCH1;
     constexpr int NSTAGE = DMA ? 3 : 2;
     constexpr int JQ = BN / 4, BROWS = 256 / JQ;     // W_MODE 1 loader shape
@@ -241,13 +250,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a, co
     auto store_tile = [&](int buf, const f32x4(&ra)[A_PASSES], const f32x4(&rb)[B_PASSES]) {
         float* Ab = As + buf * BM * APIT;
         float* Bb = Bs + buf * B_FLOATS;
+        // swizzled image: logical 16-B chunk kq of row r sits at position kq ^ ((r >> 1) & 7)
+        const int kpos = (SWZ ? (kq ^ ((r0 >> 1) & 7)) : kq) * 4;
 #pragma unroll
         for (int i = 0; i < A_PASSES; ++i)
-            *reinterpret_cast<f32x4*>(Ab + (r0 + 32 * i) * APIT + kq * 4) = ra[i];
+            *reinterpret_cast<f32x4*>(Ab + (r0 + 32 * i) * APIT + kpos) = ra[i];
         if constexpr (W_MODE == 0) {
 #pragma unroll
             for (int i = 0; i < B_PASSES; ++i)
-                *reinterpret_cast<f32x4*>(Bb + (r0 + 32 * i) * APIT + kq * 4) = rb[i];
+                *reinterpret_cast<f32x4*>(Bb + (r0 + 32 * i) * APIT + kpos) = rb[i];
         } else {
 #pragma unroll
             for (int i = 0; i < B_PASSES; ++i)
@@ -270,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a, co
         // operand fragments of k-group q+1 are read from LDS while group q is multiplied
         f32x4 af[2][TM], bf[2][TN];
         auto frags = [&](int q, f32x4(&fa)[TM], f32x4(&fb)[TN]) {
-            const int chunk = DMA ? (((2 * q + lh) ^ swz) * 4) : (q * 8 + lh * 4);
+            const int chunk = SWZ ? (((2 * q + lh) ^ swz) * 4) : (q * 8 + lh * 4);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
                 fa[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * APIT + chunk);
@@ -783,8 +794,9 @@ __global__ __launch_bounds__(256) void subgrid_fill_kernel(const ConvArgs a, con
 
 template <int BM, int BN, int WM, int WN, bool TU, int MODE, bool DMA>
 int launch_cfg(const ConvArgs& a, int M, int Krow, int KT, hipStream_t s) {
-    constexpr int APIT = DMA ? BK : APITCH;
-    constexpr int B_FLOATS = (MODE == 0) ? BN * APIT : BK * (DMA ? BN : BN + 4);
+    constexpr bool SWZ = igemm_swz<BM, BN, TU, DMA>();
+    constexpr int APIT = SWZ ? BK : APITCH;
+    constexpr int B_FLOATS = (MODE == 0) ? BN * APIT : BK * (SWZ ? BN : BN + 4);
     constexpr int NSTAGE = DMA ? 3 : 2;
     constexpr size_t lds = (size_t)(NSTAGE * BM * APIT + NSTAGE * B_FLOATS) * sizeof(float);
     static bool attr_set = false;
@@ -803,11 +815,11 @@ int launch_cfg(const ConvArgs& a, int M, int Krow, int KT, hipStream_t s) {
 // Cost model (microseconds).  A CU finishes b co-resident blocks of a config at the chip-wide rate
 // rate[b] (TFLOP/s, from the synthetic ladder tools/mfma_probe.hip, derated by what the real
 // kernels reach); the busiest CU runs ceil(blocks/256) blocks in groups of `occ`.
-struct Cfg { int bm, bn, occ; bool dma; float rate[4]; };
+struct Cfg { int bm, bn, occ; bool dma; float rate[5]; };
 const Cfg kCfg[6] = {
     {128, 128, 2, false, {100.f, 113.f, 0.f, 0.f}},     // 0: register-staged 128x128
     {128, 64, 2, false, {81.f, 100.f, 0.f, 0.f}},       // 1: register-staged 128x64
-    {64, 64, 4, false, {64.f, 90.f, 101.f, 108.f}},     // 2: register-staged 64x64
+    {64, 64, 5, false, {64.f, 90.f, 101.f, 108.f, 112.f}},   // 2: register-staged 64x64 (32 KB LDS)
     {128, 128, 1, true, {125.f, 0.f, 0.f, 0.f}},        // 3: LDS-DMA 128x128 (96 KB LDS)
     {128, 64, 2, true, {110.f, 121.f, 0.f, 0.f}},       // 4: LDS-DMA 128x64  (72 KB)
     {64, 64, 3, true, {94.f, 106.f, 111.f, 0.f}},       // 5: LDS-DMA 64x64   (48 KB)
@@ -861,6 +873,11 @@ int launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
     ConvArgs a = a_in;
     const int M = a.N * a.Ho * a.Wo;
     const bool uniform = (a.Cin % BK) == 0;
+    // the uniform path addresses both operands with 32-bit byte offsets (buffer loads)
+    CILRS_CHECK(!uniform || ((size_t)a.N * a.H * a.W * a.x_ld * sizeof(float) < (1ull << 32) &&
+                             (size_t)(a.w_mode == 0 ? a.Cout : a.Cin) * a.KH * a.KW *
+                                     (a.w_mode == 0 ? a.Cin : a.w_cin) * sizeof(float) < (1ull << 32)),
+                "conv_igemm: tensor larger than 4 GB");
     if (a.out_H == 0) {          // dense output
         a.out_H = a.Ho; a.out_W = a.Wo; a.out_sh = a.out_sw = 1; a.out_h0 = a.out_w0 = 0;
     }

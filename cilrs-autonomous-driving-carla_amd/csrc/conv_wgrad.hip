@@ -373,6 +373,10 @@ int launch_conv_wgrad(const WgradArgs& a, hipStream_t s) {
     CILRS_CHECK(a.Cin % 4 == 0 && a.x_ld % 4 == 0 && a.dy_ld % 4 == 0,
                 "conv_wgrad: Cin/x_ld/dy_ld must be multiples of 4");
     CILRS_CHECK(a.slabs != nullptr, "conv_wgrad: scratch slabs missing");
+    // both operands are addressed with 32-bit byte offsets (buffer loads)
+    CILRS_CHECK((size_t)a.N * a.H * a.W * a.x_ld * sizeof(float) < (1ull << 32) &&
+                    (size_t)a.N * a.Ho * a.Wo * a.dy_ld * sizeof(float) < (1ull << 32),
+                "conv_wgrad: tensor larger than 4 GB");
     CILRS_CHECK(((uintptr_t)a.x & 15) == 0 && ((uintptr_t)a.dy & 15) == 0 &&
                     ((uintptr_t)a.slabs & 15) == 0,
                 "conv_wgrad: pointers must be 16-byte aligned");
