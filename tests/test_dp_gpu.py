@@ -16,20 +16,21 @@ import cilrs_oracle as O
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, q, out_dir):
+def _worker(rank, world, port, q, out_dir, cfg_name):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     try:
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        from cilrs_mi355 import CILRS, CONFIG_A, Trainer
+        from cilrs_mi355 import CILRS, CONFIG_A, CONFIG_B, TrainConfig, Trainer
         from cilrs_mi355.parallel import broadcast_parameters
         torch.cuda.set_device(0)
         m = CILRS(4, dropout=0.0)
         # rank 1 starts from different weights: the broadcast must overwrite them
         m.load_state_dict(O.portable_state_dict(m.state_dict(), 0 if rank == 0 else 5), strict=True)
         m = m.cuda()
-        tr = Trainer(m, CONFIG_A, process_group=dist.group.WORLD)
+        cfg = CONFIG_A if cfg_name == "A" else TrainConfig(**{**CONFIG_B.__dict__, "dropout": 0.0})
+        tr = Trainer(m, cfg, process_group=dist.group.WORLD)
         broadcast_parameters(tr.eng, dist.group.WORLD)
         losses = []
         for step in range(2):
@@ -47,12 +48,13 @@ def _worker(rank, world, port, q, out_dir):
         q.put((rank, traceback.format_exc() + str(e), None, None))
 
 
-def test_two_rank_train_step_matches_oracle_dp_semantics(tmp_path):
+@pytest.mark.parametrize("cfg_name", ["A", "B"])
+def test_two_rank_train_step_matches_oracle_dp_semantics(tmp_path, cfg_name):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
+    port = 29600 + (os.getpid() % 2000) + (7 if cfg_name == "B" else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, str(tmp_path), cfg_name)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=600) for _ in procs), key=lambda r: r[0])
@@ -68,10 +70,11 @@ def test_two_rank_train_step_matches_oracle_dp_semantics(tmp_path):
         assert torch.equal(sd0[k], sd1[k]), k
     assert not torch.equal(sd0["visual_encoder.1.running_mean"], sd1["visual_encoder.1.running_mean"])
 
-    # oracle: per-shard gradients averaged, one Adam step -- twice
-    lr = O.CONFIG_A.lr
+    # oracle: per-shard gradients averaged, [clipped,] one Adam step -- twice
+    ocfg = O.CONFIG_A if cfg_name == "A" else O.CONFIG_B
+    lr = ocfg.lr
     reps = [O.build_oracle(0) for _ in range(2)]             # per-rank BN buffers
-    opt = O.make_optimizer(reps[0], O.CONFIG_A)
+    opt = O.make_optimizer(reps[0], ocfg)
     for step in range(2):
         grads, want_losses = [], []
         for rank in range(2):
@@ -79,12 +82,14 @@ def test_two_rank_train_step_matches_oracle_dp_semantics(tmp_path):
             m.zero_grad()
             imgs, spds, cmds, tgts = O.synthetic_batch(4, seed=60 + 10 * step + rank)[:4]
             pc, ps = m(imgs, spds, cmds)
-            loss, _ = O.compute_loss(O.CONFIG_A, pc, tgts, ps, spds)
+            loss, _ = O.compute_loss(ocfg, pc, tgts, ps, spds)
             loss.backward()
             want_losses.append(float(loss.detach()))
             grads.append([p.grad.clone() for p in m.parameters()])
         for p, a, b in zip(reps[0].parameters(), *grads):
             p.grad = (a + b) / 2
+        if ocfg.grad_clip > 0:         # clip acts on the AVERAGED gradient (nb:553-554)
+            torch.nn.utils.clip_grad_norm_(reps[0].parameters(), ocfg.grad_clip)
         opt.step()
         with torch.no_grad():
             for p0, p1 in zip(reps[0].parameters(), reps[1].parameters()):
