@@ -98,6 +98,22 @@ def same(a, b):
     return a.shape == b.shape and bool((a == b).all())
 
 
+def evaluation_schema_fixture():
+    """Key structure + published identities of the reference's own evaluation report (a data file,
+    /root/reference/evaluation_report.json:1-73): nested key names / value types, the (MSE, RMSE)
+    pairs and the per-command sample counts."""
+    r = json.load(open(os.path.join(REF, "evaluation_report.json")))
+
+    def keys(d):
+        return {k: (keys(v) if isinstance(v, dict) else type(v).__name__) for k, v in d.items()}
+    g = {"schema": keys(r), "val_samples": r["val_samples"],
+         "mse_rmse": {k: [v["MSE"], v["RMSE"]] for k, v in r["overall_metrics"].items()},
+         "per_command_n": {k: v["n"] for k, v in r["per_command_metrics"].items()},
+         "source": "/root/reference/evaluation_report.json:1-73 (key structure and the published "
+                   "MSE/RMSE, n values)"}
+    json.dump(g, open(os.path.join(OUT, "evaluation_report_schema.json"), "w"), indent=1)
+
+
 def camera_fixture(orc):
     """Whole preprocess_image incl. the resize (autonomous_drive.py:868-872, 897-902): a 600x800
     4-byte-per-pixel camera frame -> resized bytes (digest + samples) -> controls.  cv2 is absent,
@@ -251,6 +267,7 @@ def main():
     json.dump(dict(frame_seed=1234, frame_stream=7, frame_sum=int(frame.astype(np.int64).sum()),
                    cases=cases), open(os.path.join(OUT, "infer_pipeline.json"), "w"))
     camera_fixture(orc)
+    evaluation_schema_fixture()
     print("golden fixtures written to", OUT)
     for f in sorted(os.listdir(OUT)):
         print(f"  {f}: {os.path.getsize(os.path.join(OUT, f))} B")
