@@ -22,6 +22,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "cilrs-autonomous-driving-carla_amd"))
+# RCCL between processes needs dmabuf IPC on this driver (see the environment notes); keep it set
+# for every rank even when the launcher's environment lost it
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
