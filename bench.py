@@ -130,7 +130,7 @@ def main():
     def sync():
         torch.cuda.synchronize(dev)
         if world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[local])
             torch.cuda.synchronize(dev)
 
     log(f"rank {rank}/{world}: model + trainer ready, warm-up {args.warmup} steps")
