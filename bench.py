@@ -88,6 +88,11 @@ def log(msg):
 
 
 def main():
+    # stdout carries exactly ONE JSON line: everything else that writes to file descriptor 1 (this
+    # pool exports NCCL_DEBUG=VERSION and RCCL prints its banner there with printf) goes to stderr
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -306,7 +311,9 @@ def main():
 
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.batch)
-    print(json.dumps(out))
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
+    print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
 
