@@ -76,6 +76,9 @@ SIGNATURES = {
                                  vp]),
     "cilrs_bn_eval_fwd": (i32, [vp, i32, i32, vp, vp, vp, vp, f32, vp, i32, vp, vp, vp]),
     "cilrs_bn_bwd": (i32, [vp, vp, vp, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]),
+    "cilrs_linear_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "cilrs_linear_bwd": (i32, [vp, vp, vp, vp, f32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32,
+                               vp]),
     "cilrs_maxpool_fwd": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "cilrs_maxpool_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
 }

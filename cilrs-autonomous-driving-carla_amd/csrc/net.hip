@@ -1322,6 +1322,49 @@ int cilrs_augment_u8(const uint8_t* frames, const cilrs_aug_params* params, int 
                              reinterpret_cast<hipStream_t>(stream));
 }
 
+// op-level nn.Linear (the kernels the heads launch, one group)
+int cilrs_linear_fwd(const float* x, const float* w, const float* bias, float* y, int batch,
+                     int in_features, int out_features, int x_ld, int y_ld, int relu,
+                     void* stream) {
+    CILRS_CHECK(x && w && y && batch >= 1 && in_features >= 1 && out_features >= 1,
+                "linear_fwd: bad argument");
+    HGemmArgs h;
+    memset(&h, 0, sizeof(h));
+    HGemmGroup& g = h.g[0];
+    g.A = x; g.lda = x_ld; g.B = w; g.ldb = in_features; g.bias = bias; g.C = y; g.ldc = y_ld;
+    g.M = batch; g.N = out_features; g.K = in_features; g.drop_stream = kNoDrop;
+    h.ngroups = 1; h.relu = relu;
+    return launch_hgemm(0, h, reinterpret_cast<hipStream_t>(stream));
+}
+
+int cilrs_linear_bwd(const float* dy, const float* x, const float* w, const float* act,
+                     float act_scale, float* dx, float* dw, float* db, int batch,
+                     int in_features, int out_features, int dy_ld, int x_ld, int dx_ld,
+                     int act_ld, void* stream) {
+    CILRS_CHECK(dy && x && w && batch >= 1 && in_features >= 1 && out_features >= 1,
+                "linear_bwd: bad argument");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    HGemmArgs h;
+    if (dw) {
+        memset(&h, 0, sizeof(h));
+        HGemmGroup& g = h.g[0];
+        g.A = dy; g.lda = dy_ld; g.B = x; g.ldb = x_ld; g.C = dw; g.ldc = in_features;
+        g.dbias = db; g.M = out_features; g.N = in_features; g.K = batch;
+        h.ngroups = 1;
+        if (launch_hgemm(2, h, s)) return 1;
+    }
+    if (dx) {
+        memset(&h, 0, sizeof(h));
+        HGemmGroup& g = h.g[0];
+        g.A = dy; g.lda = dy_ld; g.B = w; g.ldb = in_features; g.C = dx; g.ldc = dx_ld;
+        g.mask = act; g.ldmask = act_ld; g.mask_scale = act_scale;
+        g.M = batch; g.N = in_features; g.K = out_features;
+        h.ngroups = 1;
+        if (launch_hgemm(1, h, s)) return 1;
+    }
+    return 0;
+}
+
 int cilrs_eval_acc_doubles(void) { return kEvalAccDoubles; }
 
 int cilrs_eval_accumulate(const float* controls, const float* pred_speed,

@@ -227,6 +227,17 @@ int cilrs_bn_eval_fwd(const float* y, int M, int C, const float* gamma, const fl
 int cilrs_bn_bwd(const float* dz, const float* z, const float* y, int M, int C,
                  const float* gamma, const float* stats, int relu, float* dgamma, float* dbeta,
                  float* coef3c, float* partial, float* dy, float* g_out, void* stream);
+/* nn.Linear forward  y = relu?(x W^T + b)  and backward (autonomous_drive.py:371-387; the heads'
+ * grouped kernels with one group): x [batch][in] (row pitch x_ld), w [out][in], y [batch][out].
+ * backward: dw [out][in] = dy^T x, db [out] = column sums of dy (either may be NULL together),
+ * dx [batch][in] = (dy W), kept where act > 0 and multiplied by act_scale when act != NULL. */
+int cilrs_linear_fwd(const float* x, const float* w, const float* bias, float* y, int batch,
+                     int in_features, int out_features, int x_ld, int y_ld, int relu,
+                     void* stream);
+int cilrs_linear_bwd(const float* dy, const float* x, const float* w, const float* act,
+                     float act_scale, float* dx, float* dw, float* db, int batch,
+                     int in_features, int out_features, int dy_ld, int x_ld, int dx_ld,
+                     int act_ld, void* stream);
 int cilrs_maxpool_fwd(const float* x, float* out, uint8_t* argmax, int N, int H, int W, int C,
                       void* stream);
 int cilrs_maxpool_bwd(const float* dout, const uint8_t* argmax, float* dx, int N, int H, int W,

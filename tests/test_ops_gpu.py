@@ -281,3 +281,48 @@ def test_maxpool(N, H, W):
     got = dx.cpu().permute(0, 3, 1, 2)
     assert (got[pos] - x.grad[pos]).abs().max() <= 1e-6
     assert abs(float(got.sum()) - float(x.grad.sum())) <= 1e-2
+
+
+# (batch, in, out): the heads' layer shapes plus ragged sizes (tiles are 32x32, k-groups of 8)
+LINEAR_CASES = [(128, 640, 256), (5, 640, 256), (128, 512, 256), (33, 256, 256), (128, 256, 3),
+                (7, 256, 1), (128, 1, 128), (3, 128, 128), (1, 640, 256), (70, 100, 45)]
+
+
+@pytest.mark.parametrize("B,fin,fout", LINEAR_CASES)
+@pytest.mark.parametrize("relu", [0, 1])
+def test_linear_fwd_bwd(B, fin, fout, relu):
+    """nn.Linear forward / backward as the heads launch it (grouped MFMA GEMMs, one group) vs
+    torch fp32 on the CPU; x and dx live inside wider rows (pitch in + 4) like `combined`."""
+    L = _lib()
+    lib = L.lib()
+    g = torch.Generator().manual_seed(B * 1000 + fin + fout + relu)
+    ld = fin + 4
+    xw = torch.randn(B, ld, generator=g)
+    x = xw[:, :fin]
+    w = torch.randn(fout, fin, generator=g) / max(1.0, fin ** 0.5)
+    b = torch.randn(fout, generator=g)
+    ref = x @ w.t() + b
+    if relu:
+        ref = ref.clamp_min(0)
+    dxw, wd, bd = dev(xw), dev(w), dev(b)
+    y = torch.empty(B, fout, device="cuda")
+    L.check(lib.cilrs_linear_fwd(L.ptr(dxw), L.ptr(wd), L.ptr(bd), L.ptr(y), B, fin, fout, ld,
+                                 fout, relu, stream()))
+    assert (y.cpu() - ref).abs().max() <= _tol(ref)
+    # backward: dy -> dw, db, and dx masked by an activation (the previous layer's ReLU) x 2
+    dy = torch.randn(B, fout, generator=g)
+    act = torch.randn(B, fin, generator=g)
+    ref_dw = dy.t() @ x
+    ref_db = dy.sum(0)
+    ref_dx = (dy @ w) * (act > 0) * 2.0
+    dxo = torch.full((B, ld), 7.0, device="cuda")
+    dw = torch.empty(fout, fin, device="cuda")
+    db = torch.empty(fout, device="cuda")
+    dyd, actd = dev(dy), dev(act)                        # keep the device copies alive
+    L.check(lib.cilrs_linear_bwd(L.ptr(dyd), L.ptr(dxw), L.ptr(wd), L.ptr(actd), 2.0,
+                                 L.ptr(dxo), L.ptr(dw), L.ptr(db), B, fin, fout, fout, ld, ld, fin,
+                                 stream()))
+    assert (dw.cpu() - ref_dw).abs().max() <= _tol(ref_dw)
+    assert (db.cpu() - ref_db).abs().max() <= _tol(ref_db)
+    assert (dxo.cpu()[:, :fin] - ref_dx).abs().max() <= _tol(ref_dx)
+    assert (dxo.cpu()[:, fin:] == 7.0).all()            # the row padding is untouched
