@@ -6,17 +6,25 @@
 One "step" = one pass of the hot path over one synthetic batch: forward + loss + backward +
 [gradient all-reduce] + Adam for BASELINE.json configs[1] ("CILRS training batch=128, 200x88 RGB,
 ResNet-34, Adam lr=2e-4, fp32"; Config A of SURVEY.md).  Inputs are resident in HBM before the
-timed region.  N > 1 is launched by torch.distributed.run, one rank per GPU (weak scaling: 128
-frames per GPU, RCCL all-reduce of the gradient arena overlapped with backward).
+timed region.  N > 1 runs one rank per GPU (weak scaling: 128 frames per GPU, RCCL all-reduce of
+the gradient arena overlapped with backward): either the driver starts the ranks with
+torch.distributed.run (RANK / WORLD_SIZE in the environment), or -- `python bench.py --gpus N`
+on its own -- this process starts them itself as FRESH child processes before it has made any GPU
+call, relays rank 0's JSON line and exits non-zero if any rank fails (an RCCL error included).
 
 Prints ONE JSON line (rank 0).  Besides the driver's contract it carries
   roofline      dominant kernel family (implicit-GEMM conv), hipEvent-timed on the launch stream
-  cpu_baseline  the CPU oracle (torch fp32, the reference's own arithmetic) on this host's cores
+  cpu_baseline  the CPU oracle (torch fp32, the reference's own arithmetic) on this host's cores,
+                run on the SAME batch and the SAME initial weights as the GPU: its outputs and
+                first-step loss are the parity check of this very run (parity_max_abs_err)
+  allreduce     per-bucket timing of the gradient all-reduce (N > 1, or --force-dp)
   infer_ms      single-frame inference latency (predict_controls path), median
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -50,49 +58,136 @@ def synthetic_batch(batch, seed, device):
     return [t.to(device) for t in (img, speed, cmd, tgt)], u8
 
 
-def cpu_baseline(batch, steps=2):
-    """The oracle (oracle/cilrs_oracle.py) timed on this host: `steps` Config-A train steps at
-    the same batch after one warm-up, plus 20 single-frame eval forwards."""
+def cpu_baseline(batch_cpu, state0, gpu_out, gpu_loss1, steps=3, forwards=50):
+    """The oracle (oracle/cilrs_oracle.py) on this host's cores, fed the batch the GPU timed and
+    the weights the GPU started from: (1) a train-mode forward and the first
+    train step reproduce what the GPU did before its warm-up -- outputs and loss terms must agree
+    within 1e-4 (BASELINE.json north_star), which is the parity check of THIS run; (2) `steps`
+    further Config-A train steps are timed; (3) `forwards` single-frame eval forwards are timed
+    after 5 warm-ups."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import cilrs_oracle as O
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 16))      # a 1-GPU box's CPU share is 16 cores
     torch.set_num_threads(cores)
-    m = O.build_oracle(0)
+    imgs, spds, cmds, tgts = batch_cpu
+    batch = imgs.size(0)
+    m = O.CILRSOracle(4, 0.0)
+    m.load_state_dict(state0, strict=True)
     opt = O.make_optimizer(m, O.CONFIG_A)
-    imgs, spds, cmds, tgts = O.synthetic_batch(batch, seed=1)[:4]
-    O.train_step(m, opt, O.CONFIG_A, imgs, spds, cmds, tgts)
+    m.train()
+    with torch.no_grad():
+        oc, osp = m(imgs, spds, cmds)
+    err_out = max(float((oc - gpu_out[0]).abs().max()), float((osp - gpu_out[1]).abs().max()))
+    ld, _ = O.train_step(m, opt, O.CONFIG_A, imgs, spds, cmds, tgts)      # also the warm-up
+    err_loss = max(abs(ld[k] - gpu_loss1[k]) / max(1.0, abs(ld[k])) for k in ld)
     t0 = time.perf_counter()
     for _ in range(steps):
         O.train_step(m, opt, O.CONFIG_A, imgs, spds, cmds, tgts)
     dt = time.perf_counter() - t0
     m.eval()
     with torch.no_grad():
-        for _ in range(3):
+        for _ in range(5):
             m(imgs[:1], spds[:1], cmds[:1])
         t1 = time.perf_counter()
-        for _ in range(20):
+        for _ in range(forwards):
             m(imgs[:1], spds[:1], cmds[:1])
-        infer_ms = (time.perf_counter() - t1) / 20 * 1e3
-    return dict(value=round(batch * steps / dt, 2), unit="frames/s", cores=cores, kind="port",
-                sample=f"{steps} Config-A train steps at B={batch} (after 1 warm-up) with "
-                       f"torch.set_num_threads({cores}); infer = mean of 20 B=1 eval forwards",
+        infer_ms = (time.perf_counter() - t1) / forwards * 1e3
+    base = dict(value=round(batch * steps / dt, 2), unit="frames/s", cores=cores, kind="port",
+                sample=f"{steps} Config-A train steps at B={batch} on the GPU run's own batch and "
+                       f"initial weights (after the parity step as warm-up), "
+                       f"torch.set_num_threads({cores}) = every core this process may use; "
+                       f"infer = mean of {forwards} B=1 eval forwards after 5 warm-ups",
                 infer_ms=round(infer_ms, 3))
+    return base, err_out, err_loss
+
+
+def free_port():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh ranks with
+    torch.distributed.run BEFORE this process touches the GPU (it never will), forward rank 0's
+    JSON line to stdout and everything else to stderr, return the children's exit status."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    print(f"[bench] starting {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line_out = None
+    for line in proc.stdout:
+        t = line.strip()
+        if line_out is None and t.startswith("{") and '"metric"' in t:
+            line_out = t
+        else:
+            sys.stderr.write(line)
+    rc = proc.wait()
+    if rc != 0:
+        print(f"[bench] a rank failed (exit status {rc})", file=sys.stderr, flush=True)
+        return rc
+    if line_out is None:
+        print("[bench] the ranks exited cleanly but rank 0 printed no result line",
+              file=sys.stderr, flush=True)
+        return 1
+    print(line_out, flush=True)
+    return 0
 
 
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+def rehearse(args, rank, world, real_stdout):
+    """--rehearse: the multi-rank plumbing of this file on CPU ranks (gloo) -- the launcher, the
+    rendezvous, the bucketed gradient all-reduce over a stand-in gradient arena, the barrier /
+    max-over-ranks timing and the one-line JSON relay -- WITHOUT the HIP engine.  It measures
+    nothing: tests/test_host.py uses it to cover `bench.py --gpus 2` on a box without GPUs."""
+    from cilrs_mi355 import _lib as L
+    from cilrs_mi355.engine import segment_ranges
+    from cilrs_mi355.parallel import BucketedAllReduce, bucket_plan
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = L.lib().cilrs_param_arena_floats()
+    flat = torch.full((n,), float(rank + 1))
+    red = BucketedAllReduce(flat, dist.group.WORLD, buckets=bucket_plan(segment_ranges()))
+
+    class NoEngine:
+        def run_backward(self, *a):
+            pass
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        flat.fill_(float(rank + 1))
+        red.backward_and_reduce(NoEngine(), None, None, None)
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    want = float(world * (world + 1) // 2)
+    ok = bool((flat == want).all())
+    seen = dist.get_world_size()
+    dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(f"rank {rank}: all-reduce result wrong")
+    if rank == 0:
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps({"metric": "REHEARSAL ONLY (gloo, no GPU work, nothing measured)",
+                          "value": None, "unit": "frames/s", "n_gpus": world,
+                          "n_ranks_seen": seen, "steps": args.steps, "warmup": args.warmup,
+                          "rehearsal": True, "allreduce_sum_ok": ok,
+                          "wall_s": round(float(t.item()), 4)}), flush=True)
+
+
 def main():
-    # stdout carries exactly ONE JSON line: everything else that writes to file descriptor 1 (this
-    # pool exports NCCL_DEBUG=VERSION and RCCL prints its banner there with printf) goes to stderr
-    sys.stdout.flush()
-    real_stdout = os.dup(1)
-    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -104,11 +199,30 @@ def main():
     ap.add_argument("--no-infer", action="store_true")
     ap.add_argument("--force-dp", action="store_true",
                     help="use the bucketed all-reduce path even with one rank (rehearsal)")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="CPU ranks over gloo: exercises the launcher / all-reduce / JSON relay "
+                         "only, measures nothing (tests)")
     args = ap.parse_args()
+
+    # ---- `python bench.py --gpus N` on its own: become the launcher.  Nothing above or below
+    # this point has touched the GPU in this process (importing torch does not), and the ranks
+    # are fresh child processes -- never an exec of a process that initialised HIP.
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
+    # stdout carries exactly ONE JSON line: everything else that writes to file descriptor 1 (this
+    # pool exports NCCL_DEBUG=VERSION and RCCL prints its banner there with printf) goes to stderr
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.rehearse:
+        return rehearse(args, rank, world, real_stdout)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     torch.cuda.set_device(local)
@@ -117,10 +231,10 @@ def main():
     if world > 1 or args.force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # an RCCL failure must end the job with a non-zero status, not hang the other ranks
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         pg = dist.group.WORLD
-    assert world == args.gpus or world == 1 and args.gpus == 1, \
-        f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
 
     from cilrs_mi355 import CILRS, CONFIG_A, CONFIG_B, Trainer, TrainConfig
     from cilrs_mi355.parallel import broadcast_parameters
@@ -131,6 +245,21 @@ def main():
     if pg is not None:
         broadcast_parameters(trainer.eng, pg)
     batch, u8 = synthetic_batch(args.batch, 1 + rank, dev)
+
+    # ---- parity of THIS run (rank 0, one GPU, dropout-free config): what the GPU computes from
+    # its initial weights on the batch it is about to time -- a train-mode forward and the first
+    # train step -- is recomputed by the CPU oracle in cpu_baseline() below and must agree
+    want_parity = (world == 1 and rank == 0 and not args.no_cpu_baseline and cfg.dropout == 0
+                   and args.config == "A")
+    state0 = gpu_out = gpu_loss1 = None
+    if want_parity:
+        state0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+        model.train()
+        with torch.no_grad():
+            c0, s0 = model(batch[0], batch[1], batch[2])
+        gpu_out = (c0.cpu(), s0.cpu())
+        trainer.train_step(*batch)
+        gpu_loss1 = trainer.losses()
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -157,6 +286,32 @@ def main():
     wall = float(t.item())
     loss_total = trainer.losses()["total"]
 
+    # ---- per-bucket timing of the gradient all-reduce, each bucket alone on an idle GPU (every
+    # rank takes part; in the step the buckets overlap the remaining backward)
+    ar = None
+    if pg is not None:
+        ar = []
+        for (_, b, e) in trainer.reducer.buckets:
+            view = trainer.eng.grads[b:e]
+            for _ in range(2):
+                dist.all_reduce(view, group=pg)
+            sync()
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            for _ in range(5):
+                dist.all_reduce(view, group=pg)
+            ev1.record()
+            sync()
+            ms = ev0.elapsed_time(ev1) / 5
+            tm = torch.tensor([ms], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            ms = float(tm.item())
+            ar.append({"floats": e - b, "mbytes": round((e - b) * 4 / 1e6, 2), "ms": round(ms, 4),
+                       "algbw_gbs": round((e - b) * 4 / 1e6 / max(ms, 1e-9), 1)})
+        trainer.eng.grads.zero_()
+    n_ranks_seen = dist.get_world_size() if dist.is_initialized() else 1
+
     if rank != 0:
         if dist.is_initialized():
             dist.destroy_process_group()
@@ -173,12 +328,18 @@ def main():
                                f"{args.config}, 200x88 RGB, B={args.batch}/GPU, fp32",
                    "global_batch": args.batch * world,
                    "parallelism": f"dp{world}" if world > 1 else "single"},
+        "n_ranks_seen": n_ranks_seen,
         "device_ms_per_step": round(e0.elapsed_time(e1) / args.steps, 3),
         "final_loss": round(loss_total, 6),
         "step_tflops": round(value * TRAIN_GFLOP_PER_FRAME / 1e3 / world, 2),
         "step_frac_of_f32_matrix_peak": round(
             value * TRAIN_GFLOP_PER_FRAME / 1e3 / world / PEAK_F32_MATRIX_TFLOPS, 4),
     }
+    if ar is not None:
+        out["allreduce"] = {"backend": "nccl (RCCL)", "buckets": ar,
+                            "total_ms": round(sum(x["ms"] for x in ar), 4),
+                            "note": "each bucket timed alone (max over ranks); in the step they "
+                                    "overlap the remaining backward"}
 
     log(f"{value:.1f} frames/s, {wall / args.steps * 1e3:.3f} ms/step")
     if world == 1 and args.profile_steps > 0:
@@ -208,22 +369,23 @@ def main():
         out["roofline"] = {
             "kernel": dom_name, "bound": "mfma", "achieved": round(ach, 2),
             "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_F32_MATRIX_TFLOPS, 4), "traffic": None,
+            "frac": round(ach / PEAK_F32_MATRIX_TFLOPS, 4), "traffic": None, "traffic_from": None,
             "launches_per_step": dom["calls"] // max(args.profile_steps, 1),
             "avg_launch_us": round(dom["ms"] / max(dom["calls"], 1) * 1e3, 2),
             "flops_per_launch": round(dom["flops"] / max(dom["calls"], 1), 1),
             "share_of_step": round(dom["ms"] / max(total_ms, 1e-9), 4),
         }
-        # HBM traffic per launch of that kernel family: rocprofv3 PMC passes (FETCH_SIZE doubled,
-        # WRITE_SIZE as is -- MI355X_MICROARCH.md, HBM section), measured by tools/pmc_traffic.sh
-        # on this same command and committed under profiles/
+        # HBM traffic per launch of that kernel family is NOT measured in this run: it is the
+        # committed summary of separate rocprofv3 PMC passes over this same command (FETCH_SIZE
+        # doubled, WRITE_SIZE as is -- MI355X_MICROARCH.md, HBM section; tools/pmc_traffic.sh)
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             key = "igemm" if dom is igemm else "wgrad"
             if key in tj:
                 out["roofline"]["traffic"] = tj[key]["bytes_per_launch"]
-                out["roofline"]["traffic_source"] = tj.get("source", "profiles/traffic.json")
+                out["roofline"]["traffic_from"] = "profiles/traffic.json (" + tj.get(
+                    "source", "rocprofv3 --pmc passes") + ")"
         out["kernels"] = {
             f: {"calls_per_step": a["calls"] // max(args.profile_steps, 1),
                 "ms_per_step": round(a["ms"] / args.profile_steps, 4),
@@ -309,8 +471,21 @@ def main():
         out["infer_device_us"]["total"] = round(sum(v["ms"] for v in t1.values()) / 10 * 1e3, 1)
         model.train()
 
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.batch)
+    if want_parity:
+        log("CPU oracle: parity of this run's batch + host baseline")
+        batch_cpu = [t.cpu() for t in batch]
+        base, err_out, err_loss = cpu_baseline(batch_cpu, state0, gpu_out, gpu_loss1)
+        out["cpu_baseline"] = base
+        out["parity_max_abs_err"] = float(f"{err_out:.3e}")
+        out["parity_loss_err"] = float(f"{err_loss:.3e}")
+        out["parity"] = ("train-mode forward outputs and first-step loss terms of this run's "
+                         "batch vs the CPU oracle from the same initial weights; gate 1e-4")
+        if not (err_out <= 1e-4 and err_loss <= 1e-4):
+            log(f"PARITY FAILURE: outputs {err_out:.3e}, loss {err_loss:.3e} (gate 1e-4)")
+            sys.stdout.flush()
+            os.dup2(real_stdout, 1)
+            print(json.dumps(out), flush=True)
+            raise SystemExit(3)
     sys.stdout.flush()
     os.dup2(real_stdout, 1)
     print(json.dumps(out), flush=True)

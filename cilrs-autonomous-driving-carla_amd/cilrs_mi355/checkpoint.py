@@ -61,20 +61,52 @@ def save_best(path, model, trainer, epoch, val_loss, val_steer, cmd_steer_errors
     }, path)
 
 
-def save_latest(path, model, trainer, epoch):
-    """notebook/notebook.ipynb:642-646 (+ what a resume needs)."""
-    torch.save({
+def save_latest(path, model, trainer, epoch, loop_state=None):
+    """notebook/notebook.ipynb:642-646 (+ what a resume needs: `loop_state` carries the epoch
+    loop's best_val / best_epoch / bad-epoch count / history rows, plain Python values)."""
+    d = {
         "epoch": int(epoch), "model_state_dict": model_state_dict(model),
         "optimizer_state_dict": optimizer_state_dict(trainer),
         "scheduler_state_dict": {"step_size": trainer.cfg.lr_step_size,
                                  "gamma": trainer.cfg.lr_gamma, "last_epoch": trainer.epoch,
                                  "base_lrs": [trainer.cfg.lr], "_last_lr": [trainer.lr]},
-    }, path)
+    }
+    if loop_state is not None:
+        d["loop_state"] = loop_state
+    torch.save(d, path)
+
+
+def _numpy_scalar_globals():
+    """The only non-tensor globals a checkpoint written the reference's way contains: it stores
+    ``np.mean(...)`` values (np.float64) in ``cmd_steer_errors`` (notebook/notebook.ipynb:584,
+    631-636), which is why the reference's own loader carries a numpy._core shim
+    (autonomous_drive.py:35-44).  They are allow-listed for the weights-only unpickler under both
+    module spellings (numpy 1.x wrote ``numpy.core``, 2.x writes ``numpy._core``); nothing else
+    from the file is ever executed."""
+    import numpy as np
+    try:
+        from numpy._core.multiarray import scalar
+    except ImportError:                                   # numpy 1.x
+        from numpy.core.multiarray import scalar
+    allow = [(scalar, "numpy._core.multiarray.scalar"), (scalar, "numpy.core.multiarray.scalar"),
+             np.dtype]
+    for name in ("Float64DType", "Float32DType", "Int64DType", "Int32DType", "BoolDType"):
+        t = getattr(getattr(np, "dtypes", None), name, None)
+        if t is not None:
+            allow.append(t)
+    return allow
+
+
+def load_file(path, map_location=None):
+    """torch.load with the weights-only unpickler (executes nothing from the file); numpy scalar
+    reconstruction is allow-listed so the reference's own checkpoint_best.pth loads."""
+    with torch.serialization.safe_globals(_numpy_scalar_globals()):
+        return torch.load(path, map_location=map_location or "cpu", weights_only=True)
 
 
 def load(path, model, trainer=None, map_location=None):
     """autonomous_drive.py:496-497 (+ the resume path the reference lacks)."""
-    ck = torch.load(path, map_location=map_location or "cpu", weights_only=True)
+    ck = load_file(path, map_location)
     model.load_state_dict(ck["model_state_dict"], strict=True)
     if trainer is not None and "optimizer_state_dict" in ck:
         load_optimizer_state_dict(trainer, ck["optimizer_state_dict"])

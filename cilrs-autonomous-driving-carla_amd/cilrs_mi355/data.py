@@ -196,13 +196,25 @@ class BatchLoader:
 
     def __init__(self, sessions: Sessions, indices, batch_size: int, device, train: bool,
                  seed: int = 0, workers: int = 8, height: int = IMG_HEIGHT, width: int = IMG_WIDTH,
-                 processes: bool = False):
+                 processes: bool = False, rank: int = 0, world_size: int = 1):
         """processes=True decodes in `workers` spawned processes (no GIL contention: what a
-        B=128 / 14 ms training step needs); the default thread pool starts instantly."""
+        B=128 / 14 ms training step needs); the default thread pool starts instantly.
+
+        Data parallel (rank, world_size): every rank draws the SAME epoch order from the shared
+        sampler stream (same `seed`) and keeps every world_size-th index starting at `rank`
+        (SURVEY.md 8e "rank-strided sampling"): the ranks' index sets are disjoint and their
+        union is exactly the single-process draw, so N ranks x batch B consume what one process
+        at batch N*B would.  The order is cut to a multiple of world_size * batch_size when
+        training (drop_last on the GLOBAL batch) so every rank runs the same number of steps --
+        a rank with one batch more would hang the others' all-reduce.  Augmentation parameters
+        come from a rank-offset stream."""
+        if not (0 <= rank < world_size):
+            raise ValueError(f"rank {rank} outside world of {world_size}")
         self.s, self.idx = sessions, np.asarray(indices)
         self.bs, self.device, self.train = batch_size, torch.device(device), train
         self.h, self.w = height, width
-        self.rng = np.random.default_rng(seed)
+        self.rank, self.world = rank, world_size
+        self.rng = np.random.default_rng([seed, rank])
         self.gen = torch.Generator().manual_seed(seed)
         self.workers = max(1, workers)
         self.processes = processes
@@ -238,15 +250,25 @@ class BatchLoader:
         except Exception:
             pass
 
-    def __len__(self):
+    def _shard_len(self):
         n = len(self.idx)
+        if self.train:
+            return n // (self.bs * self.world) * self.bs
+        return len(range(self.rank, n, self.world))
+
+    def __len__(self):
+        n = self._shard_len()
         return n // self.bs if self.train else (n + self.bs - 1) // self.bs
 
     def _order(self):
+        """This rank's sample order for one epoch (see __init__ for the sharding rule)."""
         if self.train:
             pick = weighted_indices(self.weights, len(self.idx), self.gen).numpy()
-            return self.idx[pick]
-        return self.idx
+            order = self.idx[pick]
+            order = order[:len(order) // (self.bs * self.world) * self.bs * self.world]
+        else:
+            order = self.idx
+        return order[self.rank::self.world]
 
     def __iter__(self):
         try:

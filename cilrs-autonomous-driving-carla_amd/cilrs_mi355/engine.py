@@ -75,6 +75,10 @@ class Plan:
         nbytes = lib.cilrs_net_workspace_bytes(handle)
         self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=device)
         assert self.workspace.data_ptr() % 256 == 0
+        # int32[4] status words inside the workspace (word 0: a command outside 0..3 was seen by
+        # the last forward -- the reference's torch.gather raises there, autonomous_drive.py:397)
+        off = lib.cilrs_net_status_offset(handle)
+        self.status = self.workspace[off:off + 16].view(torch.int32)
         self.generation = 0
 
     def __del__(self):
@@ -84,6 +88,14 @@ class Plan:
                 self.handle = None
         except Exception:
             pass
+
+    def check_status(self):
+        """Synchronising read of the status words of the last forward on this plan; raises what
+        the reference's ``all_out.gather(0, idx)`` raises for an out-of-range command."""
+        if int(self.status[0]) != 0:
+            raise RuntimeError("CILRS.forward: command index out of range (expected 0..3); "
+                               "torch.gather raises 'index out of bounds' here "
+                               "(model/autonomous_drive.py:397-398)")
 
     # per-kernel hipEvent timing ------------------------------------------------------------
     def profile(self, on: bool):
@@ -160,6 +172,8 @@ class Engine:
         self._last_param = named[-1][1]
         self.plans = {}
         self.bufs = {}
+        self.last_plan = None
+        self._scratch_grads = None        # second gradient arena (autograd accumulation only)
 
     # ------------------------------------------------------------------------------------------
     def is_attached(self) -> bool:
@@ -212,7 +226,13 @@ class Engine:
             L.ptr(controls), L.ptr(pred_speed), self._stream()))
         if train:
             pl.generation += 1
+        self.last_plan = pl
         return controls, pred_speed, pl
+
+    def check_status(self):
+        """Raise if the last forward saw an out-of-range command (one device->host read)."""
+        if self.last_plan is not None:
+            self.last_plan.check_status()
 
     def run_forward_u8(self, frames_u8, speed, command, out=None, graph=False, half=False):
         """uint8 RGB HWC frames [B,H,W,3] -> eval forward with fused preprocessing.  With
@@ -236,6 +256,7 @@ class Engine:
         L.check(fn(pl.handle, C.byref(self.bufs[(pl.batch, pl.h, pl.w)]), L.ptr(frames_u8),
                    L.ptr(speed.contiguous()), L.ptr(command.contiguous()), L.ptr(controls),
                    L.ptr(pred_speed), self._stream()))
+        self.last_plan = pl
         return controls, pred_speed
 
     def run_forward_camera(self, frames_u8, speed, command, height=88, width=200, out=None):
@@ -256,12 +277,29 @@ class Engine:
             pl.handle, C.byref(self.bufs[(pl.batch, pl.h, pl.w)]), L.ptr(frames_u8), hs, ws, px,
             ws * px, hs * ws * px, L.ptr(speed.contiguous()), L.ptr(command.contiguous()),
             L.ptr(controls), L.ptr(pred_speed), self._stream()))
+        self.last_plan = pl
         return controls, pred_speed
 
-    def run_backward(self, pl, dcontrols, dpred_speed, seg_begin=0, seg_end=6):
+    def run_backward(self, pl, dcontrols, dpred_speed, seg_begin=0, seg_end=6, into=None):
+        """Writes the parameter gradients of segments [seg_begin, seg_end) into the gradient
+        arena, or into `into` (another arena of the same layout)."""
+        bufs = self.bufs[(pl.batch, pl.h, pl.w)]
+        if into is not None:
+            bufs = L.Buffers(self.params.data_ptr(), into.data_ptr(), self.bn.data_ptr(),
+                             self.nbt.data_ptr(), pl.workspace.data_ptr())
         L.check(L.lib().cilrs_net_backward(
-            pl.handle, C.byref(self.bufs[(pl.batch, pl.h, pl.w)]), L.ptr(dcontrols),
-            L.ptr(dpred_speed), seg_begin, seg_end, self._stream()))
+            pl.handle, C.byref(bufs), L.ptr(dcontrols), L.ptr(dpred_speed), seg_begin, seg_end,
+            self._stream()))
+
+    def grads_aliased(self) -> bool:
+        """True when some parameter's .grad currently lives in the gradient arena (autograd kept
+        a view handed out by an earlier backward)."""
+        base = self.grads.untyped_storage().data_ptr()
+        for p in self.module.parameters():
+            g = p.grad
+            if g is not None and g.untyped_storage().data_ptr() == base:
+                return True
+        return False
 
     # ------------------------------------------------------------------------------------------
     def forward(self, image, speed, command, training, dropout_p, seed):
@@ -298,10 +336,17 @@ class _CILRSFunction(torch.autograd.Function):
             dcontrols = torch.zeros(b, 3, device=eng.device)
         if dpred_speed is None:
             dpred_speed = torch.zeros(b, device=eng.device)
-        eng.run_backward(pl, dcontrols.contiguous().float(), dpred_speed.contiguous().float())
-        # hand autograd its own copy: p.grad may itself alias eng.grads (accumulation would then
-        # double-count)
-        snap = eng.grads.clone()
-        grads = [_arena_view(snap, off, numel, shape)
+        # Autograd gets VIEWS of the arena the kernels wrote (no 89.7 MB copy).  Only when some
+        # p.grad already lives in that arena (autograd kept a view from an earlier backward and
+        # the caller did not reset it to None) would writing there clobber the value autograd is
+        # about to accumulate into: that backward goes to a second arena instead.
+        dst = eng.grads
+        if eng.grads_aliased():
+            if eng._scratch_grads is None:
+                eng._scratch_grads = torch.zeros_like(eng.grads)
+            dst = eng._scratch_grads
+        eng.run_backward(pl, dcontrols.contiguous().float(), dpred_speed.contiguous().float(),
+                         into=None if dst is eng.grads else dst)
+        grads = [_arena_view(dst, off, numel, shape)
                  for (_, off, numel, shape) in eng.params_layout]
         return (None, None, None, None, None, None, *grads)

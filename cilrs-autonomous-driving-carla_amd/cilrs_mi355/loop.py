@@ -29,6 +29,11 @@ def train_one_epoch(trainer, batches):
         acc = buf[:6].double().clone() if acc is None else acc + buf[:6].double()
         n += 1
     vals = (acc / max(n, 1)).tolist() if acc is not None else [float("nan")] * 6
+    if acc is not None:
+        trainer.eng.check_status()                  # out-of-range command in the last batch
+        if not all(v == v and abs(v) != float("inf") for v in vals):
+            raise FloatingPointError(f"non-finite training loss in epoch {trainer.epoch + 1}: "
+                                     f"{dict(zip(LOSS_KEYS, vals))}")
     return dict(zip(LOSS_KEYS, vals))
 
 
@@ -44,6 +49,10 @@ def fit(trainer, train_batches, val_batches, epochs=20, patience=6, out_dir=".",
     if resume:
         ck = checkpoint.load(resume, trainer.model, trainer)
         start_epoch = int(ck["epoch"]) + 1
+        st = ck.get("loop_state")
+        if st is not None:      # keep the best checkpoint / patience / history across the restart
+            best_val, best_epoch, bad = float(st["best_val"]), int(st["best_epoch"]), int(st["bad"])
+            history = [dict(r) for r in st["history"]]
         log(f"resumed from {resume} at epoch {start_epoch}")
     for epoch in range(start_epoch, epochs + 1):
         t0 = time.time()
@@ -66,7 +75,9 @@ def fit(trainer, train_batches, val_batches, epochs=20, patience=6, out_dir=".",
                                  va["steer"], cmd)
         else:
             bad += 1
-        checkpoint.save_latest(latest_path, trainer.model, trainer, epoch)   # nb:642-646
+        checkpoint.save_latest(latest_path, trainer.model, trainer, epoch,    # nb:642-646
+                               loop_state={"best_val": float(best_val), "best_epoch": best_epoch,
+                                           "bad": bad, "history": history})
         if bad >= patience:                                        # nb:650-652
             log(f"early stopping at epoch {epoch}")
             break

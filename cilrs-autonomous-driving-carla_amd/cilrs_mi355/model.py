@@ -55,6 +55,8 @@ class CILRS(nn.Module):
     def __init__(self, num_commands=4, dropout=0.0):
         super().__init__()
         if num_commands != 4:
+            # the reference's ctor is generic (autonomous_drive.py:362, 380-381) but every caller
+            # passes 4 and the kernels' arena layout is fixed ("Differences")
             raise ValueError("the HIP engine implements the reference's 4 command branches")
         self.num_commands = num_commands
         self.dropout = float(dropout)
@@ -106,6 +108,9 @@ class CILRS(nn.Module):
         seed = 0
         p = self.dropout if self.training else 0.0
         if p > 0.0:
+            from .train import dropout_seed
+            import torch.distributed as dist
+            rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
             self._dropout_calls += 1
-            seed = (torch.initial_seed() * 1000003 + self._dropout_calls) & 0xFFFFFFFFFFFFFFFF
+            seed = dropout_seed(torch.initial_seed(), self._dropout_calls, rank)
         return eng.forward(image, speed, command, self.training, p, seed)

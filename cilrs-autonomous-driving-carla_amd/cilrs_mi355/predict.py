@@ -41,6 +41,8 @@ class Predictor:
         self.spd_out_host = torch.empty(batch, dtype=torch.float32).pin_memory()
         self._ctrl_np = self.ctrl_host.numpy()
         self._spd_np = self.spd_out_host.numpy()
+        self.status_host = torch.zeros(4, dtype=torch.int32).pin_memory()
+        self._status_np = self.status_host.numpy()
         self.frames_host = torch.empty(batch, height, width, 3, dtype=torch.uint8).pin_memory()
         self.frames_dev = torch.empty(batch, height, width, 3, dtype=torch.uint8, device=dev)
         self.speed_host = torch.empty(batch, dtype=torch.float32).pin_memory()
@@ -50,6 +52,12 @@ class Predictor:
         self._frames_np = self.frames_host.numpy()
         self._speed_np = self.speed_host.numpy()
         self._cmd_np = self.cmd_host.numpy()
+
+    def _raise_on_status(self):
+        # the status words ride along with the outputs' device->host copy: a command outside
+        # 0..3 raises here exactly where the reference's torch.gather does (:397-398, :915-917)
+        if self._status_np[0] != 0:
+            raise RuntimeError("predict_controls: command index out of range (expected 0..3)")
 
     @torch.no_grad()
     def predict_batch(self, frames_u8, speeds_kmh, commands):
@@ -78,7 +86,9 @@ class Predictor:
             # two tiny D2H copies into pinned memory; no torch kernels, no allocations
             self.ctrl_host.copy_(self.ctrl_dev, non_blocking=True)
             self.spd_out_host.copy_(self.spd_out_dev, non_blocking=True)
+            self.status_host.copy_(self.eng.last_plan.status, non_blocking=True)
             self.stream.synchronize()
+        self._raise_on_status()
         out = np.empty((self.batch, 4), dtype=np.float32)
         out[:, :3] = self._ctrl_np
         out[:, 3] = self._spd_np * np.float32(SPEED_NORM_FACTOR)                # :920
@@ -115,7 +125,9 @@ class Predictor:
                                         out=(self.ctrl_dev, self.spd_out_dev))
             self.ctrl_host.copy_(self.ctrl_dev, non_blocking=True)
             self.spd_out_host.copy_(self.spd_out_dev, non_blocking=True)
+            self.status_host.copy_(self.eng.last_plan.status, non_blocking=True)
             self.stream.synchronize()
+        self._raise_on_status()
         c = self._ctrl_np[0]
         return (float(c[0]), float(c[1]), float(c[2]), float(self._spd_np[0]) * SPEED_NORM_FACTOR)
 

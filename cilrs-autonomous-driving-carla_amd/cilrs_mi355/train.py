@@ -35,6 +35,11 @@ class TrainConfig:
     lr_gamma: float = 0.5
 
 
+def dropout_seed(torch_seed: int, call: int, rank: int = 0) -> int:
+    """64-bit key of one forward's dropout masks (cilrs_net_forward `seed`)."""
+    return ((torch_seed * 1000003 + call) ^ (rank * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
+
+
 CONFIG_A = TrainConfig()
 CONFIG_B = TrainConfig(name="B", lr=1e-4, loss="l1", loss_weights=(5.0, 1.0, 1.0, 0.5),
                        grad_clip=1.0, dropout=0.5)
@@ -60,10 +65,14 @@ class Trainer:
         self._w = (C.c_float * 4)(*cfg.loss_weights)
         self._kind = 1 if cfg.loss == "l1" else 0
         self._seed_calls = 0
+        self.arena_grad_scale = 1.0
         self.reducer = None
+        self.rank = 0
         if process_group is not None:
+            import torch.distributed as dist
             from .parallel import BucketedAllReduce
             self.reducer = BucketedAllReduce(self.eng.grads, process_group)
+            self.rank = dist.get_rank(process_group)
 
     # -- pieces ---------------------------------------------------------------------------------
     def _stream(self):
@@ -96,6 +105,8 @@ class Trainer:
         lib = L.lib()
         eng, cfg = self.eng, self.cfg
         clip_ptr = None
+        # arena * arena_grad_scale = the (rank-averaged) gradient this step's clip + Adam consume
+        self.arena_grad_scale = 1.0 if cfg.grad_clip > 0 else float(grad_scale)
         if cfg.grad_clip > 0:
             if grad_scale != 1.0:
                 L.check(lib.cilrs_scale(L.ptr(eng.grads), eng.n_arena, None, grad_scale,
@@ -117,10 +128,7 @@ class Trainer:
         eng = self._ensure_engine()
         if not self.model.training:
             self.model.train()
-        seed = 0
-        if self.cfg.dropout > 0:
-            self._seed_calls += 1
-            seed = (torch.initial_seed() * 1000003 + self._seed_calls) & 0xFFFFFFFFFFFFFFFF
+        seed = self.next_dropout_seed() if self.cfg.dropout > 0 else 0
         controls, pred_speed, pl = eng.run_forward(imgs, speeds, cmds, True, self.cfg.dropout,
                                                    seed)
         # `speeds` is both an input and the speed head's regression target (nb:550)
@@ -133,10 +141,24 @@ class Trainer:
             self.optimizer_step(1.0 / self.reducer.world_size)
         return self.loss_buf
 
-    def losses(self):
-        """Host dict of the last step's loss terms (one device->host copy)."""
+    def next_dropout_seed(self):
+        """Seed of the next train step's dropout masks: torch's seed, the step count and the
+        data-parallel rank (replicas must not drop the same units)."""
+        self._seed_calls += 1
+        return dropout_seed(torch.initial_seed(), self._seed_calls, self.rank)
+
+    def losses(self, check=True):
+        """Host dict of the last step's loss terms (one device->host copy).  With check=True this
+        synchronisation point also surfaces what the reference would have raised or shown during
+        the step: an out-of-range command (torch.gather, autonomous_drive.py:397-398) and a
+        non-finite loss (the reference prints NaN from its per-step .item(), nb:523-526)."""
         v = self.loss_buf[:6].tolist()
-        return dict(zip(LOSS_KEYS, v))
+        out = dict(zip(LOSS_KEYS, v))
+        if check:
+            self.eng.check_status()
+            if not all(x == x and abs(x) != float("inf") for x in v):
+                raise FloatingPointError(f"non-finite loss after step {self.step_count}: {out}")
+        return out
 
     def grad_norm(self):
         return float(self.clip_out[0])
@@ -159,6 +181,7 @@ class Trainer:
             pc, ps = self.model(imgs, speeds, cmds)
             buf, _, _ = self.loss(pc, tgts, ps, speeds, want_grads=False)
             sums += buf[:6].double().cpu()
+            self.eng.check_status()
             n += 1
             serr = (pc[:, 0] - tgts[:, 0]).abs().double()
             cmd_sum.index_add_(0, cmds, serr)

@@ -652,6 +652,15 @@ void cilrs_net_destroy(cilrs_net* net) {
     delete net;
 }
 size_t cilrs_net_workspace_bytes(const cilrs_net* net) { return net ? net->ws_bytes : 0; }
+size_t cilrs_net_status_offset(const cilrs_net* net) { return net ? net->status_b : 0; }
+
+int cilrs_dropout(float* a, int rows, int cols, int ld, float p, uint64_t seed, int site,
+                  void* stream) {
+    CILRS_CHECK(a && rows >= 1 && cols >= 1 && ld >= cols && site >= 0 && site <= 9,
+                "dropout: bad argument");
+    return launch_dropout(a, rows, cols, ld, p, seed, (unsigned long long)site,
+                          reinterpret_cast<hipStream_t>(stream));
+}
 
 // ------------------------------------------------------------------------------------------------
 // forward

@@ -73,6 +73,23 @@ int cilrs_net_forward(cilrs_net* net, const cilrs_buffers* bufs, const float* im
                       int train, float dropout_p, uint64_t seed, float* controls,
                       float* pred_speed, void* stream);
 
+/* Byte offset, inside the workspace, of the plan's int32[4] status words.  Every forward entry
+ * zeroes them first; word 0 becomes 1 when a `command` value lies outside {0..3} -- the case in
+ * which the reference's torch.gather (autonomous_drive.py:397-398) raises.  The kernels then use
+ * branch 0 so nothing faults; the host mirror reads the word at its next synchronisation
+ * (Predictor: with the outputs; Trainer.losses() / validate()) and raises like torch does. */
+size_t cilrs_net_status_offset(const cilrs_net* net);
+
+/* nn.Dropout(p) in training mode exactly as the fused heads apply it (inverted dropout, keep
+ * where hash(seed, site, row * cols + col) >= p, kept values divided by 1 - p), in place over
+ * a [rows][cols] matrix with row pitch ld.  `site` names the Dropout module:
+ *   0 speed_encoder.2;  1 + 2k control_branches.k.2;  2 + 2k control_branches.k.5  (k = 0..3);
+ *   9 speed_predictor.2      (autonomous_drive.py:371-387).
+ * Applied to a matrix of ones it returns the mask (times 1/(1-p)) a train-mode forward with the
+ * same seed used: the parity tests feed that mask to the oracle functionally. */
+int cilrs_dropout(float* a, int rows, int cols, int ld, float p, uint64_t seed, int site,
+                  void* stream);
+
 /* Same, fed with uint8 RGB HWC frames [B,H,W,3]: fuses preprocess_image's /255, HWC->CHW and
  * Normalize(mean,std) (autonomous_drive.py:897-902; the cv2.resize is the caller's). */
 int cilrs_net_forward_u8(cilrs_net* net, const cilrs_buffers* bufs, const uint8_t* frames,

@@ -152,6 +152,40 @@ class CILRSOracle(nn.Module):
         return controls, pred_speed
 
 
+# Dropout sites in the order the HIP engine numbers them (include/cilrs_hip.h, cilrs_dropout):
+# 0 speed_encoder.2; 1 + 2k control_branches.k.2; 2 + 2k control_branches.k.5; 9 speed_predictor.2
+DROPOUT_SITES = {"speed_encoder": (0,), "speed_predictor": (9,),
+                 **{f"control_branches.{k}": (1 + 2 * k, 2 + 2 * k) for k in range(4)}}
+
+
+def _seq_with_masks(seq, x, masks, sites):
+    """nn.Sequential forward with every nn.Dropout replaced by a multiplication with the given
+    mask (values 0 or 1/(1-p)): the functional form of training-mode dropout
+    (autonomous_drive.py:371-387) under a KNOWN mask instead of torch's CPU RNG stream."""
+    it = iter(sites)
+    for layer in seq:
+        x = x * masks[next(it)] if isinstance(layer, nn.Dropout) else layer(x)
+    return x
+
+
+def forward_with_dropout_masks(model: CILRSOracle, image, speed, command, masks):
+    """CILRSOracle.forward (autonomous_drive.py:389-399) in train mode with the dropout masks
+    supplied by the caller: masks[site] has the shape of the activation that site drops."""
+    visual = model.visual_encoder(image)
+    speed_feat = _seq_with_masks(model.speed_encoder, speed.unsqueeze(1), masks,
+                                 DROPOUT_SITES["speed_encoder"])
+    combined = torch.cat([visual, speed_feat], dim=1)
+    pred_speed = _seq_with_masks(model.speed_predictor, visual, masks,
+                                 DROPOUT_SITES["speed_predictor"]).squeeze(1)
+    b = image.size(0)
+    all_out = torch.stack([_seq_with_masks(br, combined, masks,
+                                           DROPOUT_SITES[f"control_branches.{k}"])
+                           for k, br in enumerate(model.control_branches)], dim=0)
+    idx = command.unsqueeze(0).unsqueeze(2).expand(1, b, 3)
+    controls = all_out.gather(0, idx).squeeze(0)
+    return controls, pred_speed
+
+
 # --------------------------------------------------------------------------------------
 # Losses
 # --------------------------------------------------------------------------------------

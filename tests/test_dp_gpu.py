@@ -33,13 +33,23 @@ def _worker(rank, world, port, q, out_dir, cfg_name):
         tr = Trainer(m, cfg, process_group=dist.group.WORLD)
         broadcast_parameters(tr.eng, dist.group.WORLD)
         losses = []
+        extra = {}
         for step in range(2):
             imgs, spds, cmds, tgts = O.synthetic_batch(4, seed=60 + 10 * step + rank)[:4]
             tr.train_step(imgs.cuda(), spds.cuda(), cmds.cuda(), tgts.cuda())
             losses.append(tr.losses()["total"])
+            if step == 0:
+                # the gradient the optimiser consumed: the all-reduced arena times the scale the
+                # trainer folds in (1/world) -- Adam is scale-invariant, so the parameters alone
+                # cannot tell a summed gradient from an averaged one
+                extra["grads"] = {n: (g.detach().cpu() * tr.arena_grad_scale).contiguous()
+                                  for (n, _, _, _), g in zip(tr.eng.params_layout,
+                                                             tr.eng.grad_views)}
+                extra["gnorm"] = tr.grad_norm() if cfg.grad_clip > 0 else None
         torch.cuda.synchronize()
         path = os.path.join(out_dir, f"rank{rank}.pt")
         torch.save({k: v.detach().cpu() for k, v in m.state_dict().items()}, path)
+        torch.save(extra, os.path.join(out_dir, f"rank{rank}_extra.pt"))
         q.put((rank, None, losses, path))
         dist.barrier()
         dist.destroy_process_group()
@@ -88,6 +98,26 @@ def test_two_rank_train_step_matches_oracle_dp_semantics(tmp_path, cfg_name):
             grads.append([p.grad.clone() for p in m.parameters()])
         for p, a, b in zip(reps[0].parameters(), *grads):
             p.grad = (a + b) / 2
+        if step == 0:
+            # both ranks hold the same AVERAGED gradient (not the sum, not their own shard's)
+            ex = [torch.load(os.path.join(str(tmp_path), f"rank{r}_extra.pt"), weights_only=True)
+                  for r in range(2)]
+            avg_sq = own_sq = 0.0
+            for (n, p), a in zip(reps[0].named_parameters(), grads[0]):
+                want = p.grad
+                for r in range(2):
+                    got = ex[r]["grads"][n]
+                    nrm = max(float(want.norm()), 1e-12)
+                    assert float((got - want).norm()) <= 1e-2 * nrm, (n, r)
+                assert torch.equal(ex[0]["grads"][n], ex[1]["grads"][n]), n
+                avg_sq += float((want.double() ** 2).sum())
+                own_sq += float((a.double() ** 2).sum())
+            if ocfg.grad_clip > 0:
+                # clip_grad_norm_ saw the averaged gradient: its norm is neither the sum's (2x)
+                # nor one shard's
+                for r in range(2):
+                    assert abs(ex[r]["gnorm"] - avg_sq ** 0.5) <= 2e-3 * avg_sq ** 0.5
+                assert abs(own_sq ** 0.5 - avg_sq ** 0.5) > 1e-2 * avg_sq ** 0.5
         if ocfg.grad_clip > 0:         # clip acts on the AVERAGED gradient (nb:553-554)
             torch.nn.utils.clip_grad_norm_(reps[0].parameters(), ocfg.grad_clip)
         opt.step()
@@ -100,7 +130,8 @@ def test_two_rank_train_step_matches_oracle_dp_semantics(tmp_path, cfg_name):
     for (n, p) in reps[0].named_parameters():
         err = (sd0[n] - p.detach()).abs()
         assert float(err.max()) <= 2.2 * lr * 2 + 1e-6, n       # Adam's lr*sign(g) ambiguity
-        assert int((err > 2e-5).sum()) <= max(4, int(0.6 * err.numel())), n
+        # two steps in: same gate as tests/test_model_gpu.py::_close_params (measured fractions)
+        assert int((err > 2e-5).sum()) <= max(6, int(2e-3 * err.numel())), n
     # rank 1's BN statistics followed ITS shard
     want_rm1 = reps[1].state_dict()["visual_encoder.1.running_mean"]
     # (step 2 starts from parameters that differ by Adam's lr*sign(g) ambiguity: 1e-4, not 1e-5)

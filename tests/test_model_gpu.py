@@ -11,8 +11,16 @@ Tolerances (BASELINE.json north_star: "within 1e-4 fp32 on identical batches"):
                   O(1) ReLU / max-pool decisions per step (each a ~1e-3 relative perturbation of
                   everything upstream), so tighter fp32-vs-fp32 bounds are not meaningful; the
                   kernels' own precision is pinned by tests/test_ops_gpu.py (2e-5 .. 5e-5)
-  params after k Adam steps   Adam moves every element by ~lr*sign(g): <= 2.2*lr*k max, and
-                  all but 0.2 % of the elements within 2e-5
+  params after k Adam steps   Adam moves an element whose gradient is within fp32 noise of zero
+                  by +-lr per step whatever the implementation, so: hard bound 2.2*lr*k on every
+                  element, and the FRACTION of elements beyond 2e-5 gated at ~10x what
+                  tools/param_outliers.py measures on MI355X (see _close_params); the optimiser's
+                  own arithmetic is pinned element-wise at 1e-6 over five steps by
+                  tests/test_ops_gpu.py::test_adam_step_matches_torch_adam
+  B = 128         one whole fused train step per config against the oracle at the benchmark
+                  batch (other tiles / split-K / slab plans than at B = 8)
+  dropout         Config B as executed (p = 0.5): the masks the kernels used are regenerated
+                  through the C-ABI (cilrs_dropout) and fed to the oracle functionally
 """
 import json
 import os
@@ -114,17 +122,21 @@ def _fp64_grads(ocfg, imgs, spds, cmds, tgts):
     return {n: p.grad for n, p in m64.named_parameters()}
 
 
+# Fraction of a tensor's elements allowed to differ by more than 2e-5 after k Adam steps, and the
+# count allowed in tensors too small for a fraction to mean anything.  Measured on MI355X with
+# tools/param_outliers.py (profiles/r02_param_outliers.log): see OUTLIER_FRAC below.
+OUTLIER_FRAC = {1: 2e-4, 2: 2e-3, 3: 5e-3}
+OUTLIER_FLOOR = 6
+
+
 def _close_params(mine, want, lr, steps):
     """Adam's update is ~lr*sign(g) per step, so an element whose gradient is within rounding of
     zero may legitimately differ by 2*lr per step; everything else must agree to ~1e-6."""
     err = (mine - want).abs()
     assert float(err.max()) <= 2.2 * lr * steps + 1e-6
-    # gradients carry ~1e-3 relative fp32 noise (see the gradient budget): elements whose
-    # |g| is below that noise may take the other sign; >= 95 % of every tensor agrees closely
-    # after later steps the trajectories have drifted (different m/v history), so only the hard
-    # bound above is meaningful there
-    frac = 0.1 if steps == 1 else 0.6
-    assert int((err > 2e-5).sum()) <= max(4, int(frac * err.numel()))
+    nbad = int((err > 2e-5).sum())
+    assert nbad <= max(OUTLIER_FLOOR, int(OUTLIER_FRAC[min(steps, 3)] * err.numel())), \
+        (nbad, err.numel())
 
 
 @pytest.mark.parametrize("cfg_name", ["A", "B"])
@@ -572,3 +584,309 @@ def test_full_batch_properties_b128():
     eng.run_backward(pl, 2.0 * dc, 2.0 * dp)
     g2 = eng.grads
     assert torch.equal(g2, 2.0 * g1)            # exact: scaling by 2 commutes with fp32 rounding
+
+
+# ---- round 2: the benchmark batch, dropout with known masks, status words -----------------------
+def _grad_budget_check(tag, named_oracle_params, gv, g64, coef):
+    """Per-tensor relative-L2 error of the HIP gradients against float64, budgeted against the
+    fp32 CPU oracle's own error; returns 1 - cos of the full gradient."""
+    dot = n1 = n2 = 0.0
+    worst_gpu = worst_cpu = 0.0
+    errs = []
+    for n, p in named_oracle_params:
+        mine = gv[n].detach().cpu().double() * coef
+        ref64 = g64[n] * coef
+        nrm = max(float(ref64.norm()), 1e-30)
+        e_gpu = float((mine - ref64).norm()) / nrm
+        e_cpu = float((p.grad.double() - ref64).norm()) / nrm
+        assert e_gpu <= max(4.0 * e_cpu, 5e-3), (tag, n, e_gpu, e_cpu)
+        gmax = max(float(ref64.abs().max()), 1e-12)
+        assert float((mine - ref64).abs().max()) <= 5e-2 * gmax, (tag, n)
+        worst_gpu, worst_cpu = max(worst_gpu, e_gpu), max(worst_cpu, e_cpu)
+        errs.append((e_gpu, e_cpu))
+        dot += float((mine * ref64).sum())
+        n1 += float((mine ** 2).sum())
+        n2 += float((ref64 ** 2).sum())
+    med_gpu = sorted(e[0] for e in errs)[len(errs) // 2]
+    med_cpu = sorted(e[1] for e in errs)[len(errs) // 2]
+    cos = dot / (n1 ** 0.5 * n2 ** 0.5)
+    print(f"{tag}: per-tensor relative-L2 grad error vs float64: HIP worst {worst_gpu:.3e} median "
+          f"{med_gpu:.3e}; CPU-fp32 oracle worst {worst_cpu:.3e} median {med_cpu:.3e}; "
+          f"1-cos(all grads) = {1 - cos:.3e}")
+    assert med_gpu <= max(10.0 * med_cpu, 1e-4)
+    return 1.0 - cos
+
+
+@pytest.mark.parametrize("cfg_name", ["A", "B"])
+def test_train_step_b128_vs_oracle(cfg_name):
+    """BASELINE configs[1] at its full size: ONE fused train step at B = 128 (forward with batch
+    statistics, loss, backward, [clip], Adam) against the CPU oracle on the same batch -- six loss
+    terms, train-mode outputs, every BatchNorm layer's running statistics, per-tensor gradients
+    against a float64 run of the same step, the clip norm, and the parameters after Adam.  At this
+    size every convolution runs the plan the benchmark times (other tiles, split-K factors and
+    K-slab counts than the B = 8 fixtures)."""
+    from cilrs_mi355 import Trainer
+    torch.set_num_threads(max(1, len(os.sched_getaffinity(0))))
+    cfg, ocfg = _cfgs()[cfg_name]
+    B = 128
+    imgs, spds, cmds, tgts = O.synthetic_batch(B, seed=4242)[:4]
+    m = make_model()
+    tr = Trainer(m, cfg)
+    eng = tr.eng
+    # the step, piecewise through the same entry points train_step uses, to see its outputs
+    m.train()
+    controls, pred_speed, pl = eng.run_forward(*to_dev(imgs, spds, cmds), True, 0.0, 0)
+    _, dc, dp = tr.loss(controls, tgts.cuda(), pred_speed, spds.cuda())
+    eng.run_backward(pl, dc, dp)
+    tr.optimizer_step(1.0)
+    got = tr.losses()
+    # oracle, fp32 (the reference path) and float64 (ground truth of the gradient budget)
+    orc = O.build_oracle(0)
+    oopt = O.make_optimizer(orc, ocfg)
+    orc.train()
+    with torch.no_grad():
+        probe = O.build_oracle(0).train()
+        oc, osp = probe(imgs, spds, cmds)
+    assert (controls.cpu() - oc).abs().max() <= TOL_OUT
+    assert (pred_speed.cpu() - osp).abs().max() <= TOL_OUT
+    g64 = _fp64_grads(ocfg, imgs, spds, cmds, tgts)
+    old, ognorm = O.train_step(orc, oopt, ocfg, imgs, spds, cmds, tgts)
+    for k, v in old.items():
+        assert abs(got[k] - v) <= 1e-4 * max(1.0, abs(v)), (k, got[k], v)
+    coef = 1.0
+    if cfg.grad_clip > 0:
+        gn = tr.grad_norm()
+        assert abs(gn - ognorm) <= 5e-4 * ognorm, (gn, ognorm)
+        n64 = float(torch.sqrt(sum((g.double() ** 2).sum() for g in g64.values())))
+        assert abs(gn - n64) <= 5e-4 * n64
+        coef = min(1.0, cfg.grad_clip / (n64 + 1e-6))
+    omc = _grad_budget_check(f"B=128 cfg {cfg_name}", list(orc.named_parameters()),
+                             _grad_views(eng), g64, coef)
+    assert omc <= 1e-5
+    # train-mode BatchNorm at B = 128: running statistics of all 36 layers, element-wise
+    sd, osd = m.state_dict(), orc.state_dict()
+    for k, v in osd.items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert (sd[k].cpu() - v).abs().max() <= 1e-5 * max(1.0, float(v.abs().max())), k
+        elif k.endswith("num_batches_tracked"):
+            assert int(sd[k]) == int(v) == 1
+    pv = dict(m.named_parameters())
+    for n, p in orc.named_parameters():
+        _close_params(pv[n].detach().cpu(), p.detach(), cfg.lr, 1)
+
+
+def _dropout_masks(B, p, seed):
+    """The masks (0 or 1/(1-p)) a train-mode forward with `seed` applies, regenerated through the
+    C-ABI with the kernels' own hash (include/cilrs_hip.h: cilrs_dropout)."""
+    import ctypes as C
+    from cilrs_mi355 import _lib as L
+    widths = {0: 128, 9: 256, **{s: 256 for s in range(1, 9)}}
+    masks = {}
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for site, cols in widths.items():
+        t = torch.ones(B, cols, device="cuda")
+        L.check(L.lib().cilrs_dropout(L.ptr(t), B, cols, cols, p, seed, site, st))
+        masks[site] = t.cpu()
+    torch.cuda.synchronize()
+    return masks
+
+
+def test_dropout_train_step_matches_oracle_under_the_same_masks():
+    """Config B as the notebook executed it (dropout 0.5, notebook/notebook.ipynb:480, 549-555).
+    torch's CPU RNG stream cannot be reproduced on the device, so parity is functional: the masks
+    the fused heads applied (same seed, same counter-based hash, read back through cilrs_dropout)
+    are given to the oracle, whose forward then multiplies by them where nn.Dropout sits.
+    Outputs, the six loss terms, the clip norm and every gradient tensor must agree."""
+    from cilrs_mi355 import CONFIG_B, Trainer
+    from cilrs_mi355.train import dropout_seed
+    B, p = 24, 0.5
+    torch.manual_seed(2025)
+    imgs, spds, cmds, tgts = O.synthetic_batch(B, seed=77)[:4]
+    m = make_model(dropout=p)
+    tr = Trainer(m, CONFIG_B)
+    assert tr.cfg.dropout == p
+    seed = dropout_seed(torch.initial_seed(), 1, 0)
+    eng = tr.eng
+    m.train()
+    controls, pred_speed, pl = eng.run_forward(*to_dev(imgs, spds, cmds), True, p, seed)
+    _, dc, dp = tr.loss(controls, tgts.cuda(), pred_speed, spds.cuda())
+    eng.run_backward(pl, dc, dp)
+    tr.optimizer_step(1.0)
+    got = tr.losses()
+    masks = _dropout_masks(B, p, seed)
+    for site, t in masks.items():
+        vals = set(t.unique().tolist())
+        assert vals == {0.0, 2.0}, (site, vals)                   # 0 or 1/(1-p)
+        assert 0.4 <= float((t == 0).float().mean()) <= 0.6      # about half dropped
+    assert not torch.equal(masks[1], masks[3]) and not torch.equal(masks[1], masks[2])
+    # oracle under those masks: fp32 and float64
+    orc = O.build_oracle(0).train()
+    oc, osp = O.forward_with_dropout_masks(orc, imgs, spds, cmds, masks)
+    loss, old = O.compute_loss(O.CONFIG_B, oc, tgts, osp, spds)
+    orc.zero_grad()
+    loss.backward()
+    assert (controls.cpu() - oc.detach()).abs().max() <= TOL_OUT
+    assert (pred_speed.cpu() - osp.detach()).abs().max() <= TOL_OUT
+    for k, v in old.items():
+        assert abs(got[k] - v) <= 1e-4 * max(1.0, abs(v)), (k, got[k], v)
+    m64 = O.build_oracle(0).double().train()
+    c64, s64 = O.forward_with_dropout_masks(m64, imgs.double(), spds.double(), cmds,
+                                            {k: v.double() for k, v in masks.items()})
+    l64, _ = O.compute_loss(O.CONFIG_B, c64, tgts.double(), s64, spds.double())
+    l64.backward()
+    g64 = {n: q.grad for n, q in m64.named_parameters()}
+    n64 = float(torch.sqrt(sum((g ** 2).sum() for g in g64.values())))
+    gn = tr.grad_norm()
+    assert abs(gn - n64) <= 5e-4 * n64, (gn, n64)
+    coef = min(1.0, CONFIG_B.grad_clip / (n64 + 1e-6))
+    omc = _grad_budget_check("dropout 0.5", list(orc.named_parameters()), _grad_views(eng), g64,
+                             1.0)
+    assert omc <= 1e-5
+    # dropping a unit silences exactly its outgoing weights' gradient rows for that sample; a
+    # different seed must give different gradients (the masks matter)
+    tr2 = Trainer(make_model(dropout=p), CONFIG_B)
+    eng2 = tr2.eng
+    tr2.model.train()
+    c2, s2, pl2 = eng2.run_forward(*to_dev(imgs, spds, cmds), True, p, seed + 1)
+    assert (c2 - controls).abs().max() > 1e-3
+    # the one-call train step draws the same seed sequence (rank 0): bit-identical parameters
+    torch.manual_seed(2025)
+    m3 = make_model(dropout=p)
+    tr3 = Trainer(m3, CONFIG_B)
+    tr3.train_step(*to_dev(imgs, spds, cmds, tgts))
+    assert tr3.losses() == got
+    assert torch.equal(tr3.eng.params, eng.params)
+    assert coef <= 1.0
+
+
+@pytest.mark.parametrize("B", [1, 16, 17])
+@pytest.mark.parametrize("bad", [4, -1])
+def test_out_of_range_command_raises_like_torch_gather(B, bad):
+    """The reference's all_out.gather(0, idx) raises for a command outside 0..3
+    (autonomous_drive.py:397-398).  The kernels flag it in the plan's status word; the host
+    mirror raises at its next synchronisation: Engine.check_status(), Trainer.losses(),
+    Trainer.validate() and Predictor.predict_controls -- on both head paths (B <= 16: commanded
+    branch only; B >= 17: all four branches + gather) and in training."""
+    from cilrs_mi355 import CONFIG_A, Trainer
+    from cilrs_mi355.predict import Predictor
+    m = make_model().eval()
+    img, spd, cmd, tgt, _ = O.synthetic_batch(B, seed=3)
+    with torch.no_grad():
+        m(*to_dev(img, spd, cmd))
+    m.engine().check_status()                                   # a good batch passes
+    cmd_bad = cmd.clone()
+    cmd_bad[B // 2] = bad
+    with pytest.raises(Exception):                              # what torch does on the CPU
+        O.build_oracle(0).eval()(img, spd, cmd_bad)
+    with torch.no_grad():
+        c, s = m(*to_dev(img, spd, cmd_bad))
+    assert torch.isfinite(c).all() and torch.isfinite(s).all()  # nothing faulted
+    with pytest.raises(RuntimeError, match="out of range"):
+        m.engine().check_status()
+    with torch.no_grad():
+        m(*to_dev(img, spd, cmd))
+    m.engine().check_status()                                   # the flag is per forward
+    tr = Trainer(m, CONFIG_A)
+    with pytest.raises(RuntimeError, match="out of range"):
+        tr.validate([to_dev(img, spd, cmd_bad, tgt)])
+    if B > 1:
+        tr.train_step(*to_dev(img, spd, cmd_bad, tgt))
+        with pytest.raises(RuntimeError, match="out of range"):
+            tr.losses()
+        tr.train_step(*to_dev(img, spd, cmd, tgt))
+        assert np.isfinite(tr.losses()["total"])
+    if B == 1:
+        pr = Predictor(m)
+        frame = np.zeros((88, 200, 3), np.uint8)
+        pr.predict_controls(frame, 10.0, 3)
+        with pytest.raises(RuntimeError, match="out of range"):
+            pr.predict_controls(frame, 10.0, bad)
+        assert len(pr.predict_controls(frame, 10.0, 0)) == 4
+
+
+def test_non_finite_loss_is_reported():
+    """A NaN target poisons the loss; Trainer.losses() raises instead of returning it silently
+    (NaN/Inf guard on the loss scalar)."""
+    from cilrs_mi355 import CONFIG_A, Trainer
+    m = make_model()
+    tr = Trainer(m, CONFIG_A)
+    imgs, spds, cmds, tgts = O.synthetic_batch(4, seed=8)[:4]
+    tgts[1, 0] = float("nan")
+    tr.train_step(*to_dev(imgs, spds, cmds, tgts))
+    with pytest.raises(FloatingPointError):
+        tr.losses()
+    assert tr.losses(check=False)["total"] != tr.losses(check=False)["total"]      # NaN
+
+
+def test_autograd_backward_hands_out_arena_views_and_accumulates_correctly():
+    """loss.backward() through the autograd bridge (notebook/notebook.ipynb:552) no longer clones
+    the 89.7 MB gradient arena: with p.grad None the gradients are views of the arena; when
+    autograd kept such a view (zero_grad(set_to_none=False), or gradient accumulation over two
+    backward passes) the next backward is written to a second arena so accumulation stays
+    correct."""
+    imgs, spds, cmds, tgts = to_dev(*O.synthetic_batch(4, seed=31)[:4])
+    mse = torch.nn.functional.mse_loss
+
+    def loss_of(m):
+        pc, ps = m(imgs, spds, cmds)
+        return mse(pc, tgts) + 0.05 * mse(ps, spds)
+
+    m = make_model().train()
+    loss_of(m).backward()
+    eng = m.engine()
+    g1 = {n: p.grad.detach().clone() for n, p in m.named_parameters()}
+    # second backward WITHOUT zeroing: p.grad must become exactly 2x (same batch, BN statistics
+    # do not depend on the running buffers in train mode)
+    loss_of(m).backward()
+    for n, p in m.named_parameters():
+        assert torch.allclose(p.grad, 2 * g1[n], rtol=0, atol=1e-6 * float(g1[n].abs().max() + 1e-30)), n
+    # zero in place, then one more backward: back to 1x
+    for p in m.parameters():
+        p.grad.zero_()
+    loss_of(m).backward()
+    for n, p in m.named_parameters():
+        assert torch.equal(p.grad, g1[n]), n
+    # set_to_none path
+    m.zero_grad(set_to_none=True)
+    loss_of(m).backward()
+    for n, p in m.named_parameters():
+        assert torch.equal(p.grad, g1[n]), n
+    assert eng is m.engine()
+
+
+def test_fit_resume_keeps_best_checkpoint_patience_and_history(tmp_path):
+    """Resuming from checkpoint_latest.pth restores the epoch loop's own state: a worse epoch
+    after the restart must not overwrite checkpoint_best.pth, the patience counter continues and
+    training_history.csv keeps the rows written before the restart."""
+    from cilrs_mi355 import CONFIG_A, Trainer, checkpoint
+    from cilrs_mi355.loop import fit
+    val = [to_dev(*O.synthetic_batch(4, seed=20 + i)[:4]) for i in range(2)]
+    train = [to_dev(*O.synthetic_batch(4, seed=70 + i)[:4]) for i in range(2)]
+    m = make_model()
+    tr = Trainer(m, CONFIG_A)
+    res = fit(tr, lambda: train, lambda: val, epochs=2, patience=6, out_dir=str(tmp_path),
+              log=lambda *_: None)
+    best_before = checkpoint.load_file(str(tmp_path / "checkpoint_best.pth"))
+    latest = checkpoint.load_file(str(tmp_path / "checkpoint_latest.pth"))
+    assert latest["loop_state"]["best_epoch"] == res["best_epoch"]
+    assert len(latest["loop_state"]["history"]) == 2
+    # restart in a fresh model / trainer; make every later epoch WORSE (huge learning rate)
+    m2 = make_model(seed=4)
+    tr2 = Trainer(m2, CONFIG_A)
+    logs = []
+
+    def noisy_train():
+        tr2.lr = 0.05
+        return train
+    res2 = fit(tr2, noisy_train, lambda: val, epochs=4, patience=2,
+               out_dir=str(tmp_path), resume=str(tmp_path / "checkpoint_latest.pth"),
+               log=logs.append)
+    assert res2["best_epoch"] == res["best_epoch"]
+    assert res2["best_val_loss"] == res["best_val_loss"]
+    best_after = checkpoint.load_file(str(tmp_path / "checkpoint_best.pth"))
+    assert best_after["epoch"] == best_before["epoch"]
+    assert torch.equal(best_after["model_state_dict"]["visual_encoder.0.weight"],
+                       best_before["model_state_dict"]["visual_encoder.0.weight"])
+    rows = open(tmp_path / "training_history.csv").read().strip().split("\n")
+    assert [r.split(",")[0] for r in rows[1:3]] == ["1", "2"] and len(rows) >= 4
+    assert any("early stopping" in str(l) for l in logs) or len(rows) == 5

@@ -326,3 +326,173 @@ def test_linear_fwd_bwd(B, fin, fout, relu):
     assert (db.cpu() - ref_db).abs().max() <= _tol(ref_db)
     assert (dxo.cpu()[:, :fin] - ref_dx).abs().max() <= _tol(ref_dx)
     assert (dxo.cpu()[:, fin:] == 7.0).all()            # the row padding is untouched
+
+
+# ---- round 2: the plans that the benchmark actually runs (N = 128) ------------------------------
+# The ten distinct convolution shapes of the ResNet-34 trunk at the benchmark batch (BASELINE.json
+# configs[1]: B = 128).  At this size the launchers pick other tiles, split-K factors and K-slab
+# counts than at the small batches above (conv_wgrad<128> with grid.z slabs, split-K reduces that
+# emit BatchNorm partials, five 64x64 blocks per CU, ...), so every op is checked here with the
+# AUTO plan against torch's CPU convolution and its autograd.
+TRUNK_SHAPES = [
+    (22, 50, 64, 64, 3, 1, 1),       # layer1 3x3
+    (22, 50, 64, 128, 3, 2, 1),      # layer2.0.conv1
+    (22, 50, 64, 128, 1, 2, 0),      # layer2.0.downsample
+    (11, 25, 128, 128, 3, 1, 1),     # layer2 3x3
+    (11, 25, 128, 256, 3, 2, 1),     # layer3.0.conv1
+    (11, 25, 128, 256, 1, 2, 0),     # layer3.0.downsample
+    (6, 13, 256, 256, 3, 1, 1),      # layer3 3x3
+    (6, 13, 256, 512, 3, 2, 1),      # layer4.0.conv1
+    (6, 13, 256, 512, 1, 2, 0),      # layer4.0.downsample
+    (3, 7, 512, 512, 3, 1, 1),       # layer4 3x3
+]
+# split-K scratch the plan hands every convolution at B = 128 (net.hip: 8 x the largest tensor of
+# at most 6 M floats = layer2's 35,200 x 128 output) -- the cost model's choices depend on it
+PLAN_KSPLIT_FLOATS = 8 * 128 * 11 * 25 * 128
+
+
+@pytest.mark.parametrize("shape", TRUNK_SHAPES)
+def test_conv_auto_plan_at_benchmark_batch(shape):
+    L = _lib()
+    lib = L.lib()
+    N = 128
+    H, W, Cin, Cout, k, s, p = shape
+    torch.set_num_threads(max(1, len(__import__("os").sched_getaffinity(0))))
+    g = torch.Generator().manual_seed(100 + Cin + Cout + k)
+    x = torch.randn(N, Cin, H, W, generator=g, requires_grad=True)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (k * k * Cin) ** 0.5).requires_grad_(True)
+    y = F.conv2d(x, w, None, s, p)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    Ho, Wo = y.shape[2], y.shape[3]
+    xd, wd, dyd = nhwc(x.detach()), ohwi(w.detach()), nhwc(dy)
+    scratch = torch.empty(PLAN_KSPLIT_FLOATS, device="cuda")
+    # forward
+    yd = torch.full((N, Ho, Wo, Cout), float("nan"), device="cuda")
+    L.check(lib.cilrs_conv2d_fwd(L.ptr(xd), L.ptr(wd), L.ptr(yd), N, H, W, Cin, Cout, k, k, s, p,
+                                 -1, 0, L.ptr(scratch), scratch.numel(), stream()))
+    # data gradient, plain and with the residual gradient added in the epilogue
+    dxd = torch.full((N, H, W, Cin), float("nan"), device="cuda")
+    L.check(lib.cilrs_conv2d_dgrad(L.ptr(dyd), L.ptr(wd), L.ptr(dxd), None, N, H, W, Cin, Cout, k,
+                                   k, s, p, -1, 0, L.ptr(scratch), scratch.numel(), stream()))
+    add = torch.randn(N, H, W, Cin, generator=g)
+    addd = dev(add)
+    dxa = torch.full((N, H, W, Cin), float("nan"), device="cuda")
+    L.check(lib.cilrs_conv2d_dgrad(L.ptr(dyd), L.ptr(wd), L.ptr(dxa), L.ptr(addd), N, H, W, Cin,
+                                   Cout, k, k, s, p, -1, 0, L.ptr(scratch), scratch.numel(),
+                                   stream()))
+    # weight gradient
+    nsc = lib.cilrs_conv2d_wgrad_scratch_floats(N, H, W, Cin, Cout, k, k, s, p)
+    slabs = torch.empty(nsc, device="cuda")
+    dwd = torch.full((Cout, k, k, Cin), float("nan"), device="cuda")
+    L.check(lib.cilrs_conv2d_wgrad(L.ptr(xd), L.ptr(dyd), L.ptr(dwd), L.ptr(slabs), N, H, W, Cin,
+                                   Cout, k, k, s, p, Cin, stream()))
+    torch.cuda.synchronize()
+    got_y = yd.cpu().permute(0, 3, 1, 2)
+    ref_y = y.detach()
+    assert torch.isfinite(got_y).all()
+    assert (got_y - ref_y).abs().max() <= _tol(ref_y)
+    want_dx = x.grad.permute(0, 2, 3, 1)
+    got_dx = dxd.cpu()
+    assert torch.isfinite(got_dx).all()
+    assert (got_dx - want_dx).abs().max() <= _tol(want_dx)
+    assert (dxa.cpu() - (want_dx + add)).abs().max() <= _tol(want_dx + add)
+    # K = N*Ho*Wo products per element (up to 140,800): summation-order noise grows like sqrt(K)
+    want_dw = w.grad.permute(0, 2, 3, 1)
+    got_dw = dwd.cpu()
+    assert torch.isfinite(got_dw).all()
+    err = (got_dw - want_dw).abs().max()
+    assert err <= _tol(want_dw, 5e-5), float(err / want_dw.abs().max())
+    rel = float((got_dw.double() - want_dw.double()).norm() / want_dw.double().norm())
+    assert rel <= 2e-6, rel
+
+
+def test_stem_auto_plan_at_benchmark_batch():
+    """conv 7x7 / s2 / p3 with Cin padded 3 -> 4 at N = 128: forward and weight gradient."""
+    L = _lib()
+    lib = L.lib()
+    N, H, W = 128, 88, 200
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(N, 3, H, W, generator=g)
+    w = (torch.randn(64, 3, 7, 7, generator=g) / 147 ** 0.5).requires_grad_(True)
+    y = F.conv2d(x, w, None, 2, 3)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    x4 = torch.zeros(N, H, W, 4)
+    x4[..., :3] = x.permute(0, 2, 3, 1)
+    w4 = torch.zeros(64, 7, 7, 4)
+    w4[..., :3] = w.detach().permute(0, 2, 3, 1)
+    x4d, w4d, dyd = dev(x4), dev(w4), nhwc(dy)
+    scratch = torch.empty(PLAN_KSPLIT_FLOATS, device="cuda")
+    yd = torch.full((N, 44, 100, 64), float("nan"), device="cuda")
+    L.check(lib.cilrs_conv2d_fwd(L.ptr(x4d), L.ptr(w4d), L.ptr(yd), N, H, W, 4, 64, 7, 7, 2, 3, -1,
+                                 0, L.ptr(scratch), scratch.numel(), stream()))
+    nsc = lib.cilrs_conv2d_wgrad_scratch_floats(N, H, W, 4, 64, 7, 7, 2, 3)
+    slabs = torch.empty(nsc, device="cuda")
+    dwd = torch.full((64, 7, 7, 3), float("nan"), device="cuda")
+    L.check(lib.cilrs_conv2d_wgrad(L.ptr(x4d), L.ptr(dyd), L.ptr(dwd), L.ptr(slabs), N, H, W, 4,
+                                   64, 7, 7, 2, 3, 3, stream()))
+    torch.cuda.synchronize()
+    ref = y.detach()
+    assert (yd.cpu().permute(0, 3, 1, 2) - ref).abs().max() <= _tol(ref)
+    want_dw = w.grad.permute(0, 2, 3, 1)
+    got = dwd.cpu()
+    assert torch.isfinite(got).all()
+    assert (got - want_dw).abs().max() <= _tol(want_dw, 5e-5)
+    assert float((got.double() - want_dw.double()).norm() / want_dw.double().norm()) <= 2e-6
+
+
+@pytest.mark.parametrize("clip,gscale", [(False, 1.0), (True, 0.5)])
+def test_adam_step_matches_torch_adam(clip, gscale):
+    """cilrs_adam_step vs torch.optim.Adam (coupled L2 weight decay, bias correction, eps outside
+    the sqrt -- notebook/notebook.ipynb:533-534, 555) element by element over five steps with
+    fresh gradients each step, so the first/second-moment history, the bias corrections and the
+    weight decay all matter (step 1 alone is lr*sign(g) whatever the hyper-parameters are).  With
+    clip: the device coefficient of cilrs_grad_sqnorm scales the gradient, and grad_scale (the
+    1/world_size of data-parallel sums) multiplies it too."""
+    L = _lib()
+    lib = L.lib()
+    n = 100_003 * 4            # the arenas are float4-granular
+    lr, b1, b2, eps, wd, max_norm = 2e-4, 0.9, 0.999, 1e-8, 1e-4, 1.0
+    g = torch.Generator().manual_seed(9)
+    p0 = torch.randn(n, generator=g)
+    p_ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([p_ref], lr=lr, betas=(b1, b2), eps=eps, weight_decay=wd)
+    pd = p0.cuda()
+    m = torch.zeros(n, device="cuda")
+    v = torch.zeros(n, device="cuda")
+    clip_out = torch.zeros(2, device="cuda")
+    scr = torch.empty(lib.cilrs_sqnorm_scratch_bytes(), dtype=torch.uint8, device="cuda")
+    for step in range(1, 6):
+        # gradients of very different magnitudes, some exactly zero, rescaled every step
+        gr = torch.randn(n, generator=g) * (10.0 ** torch.randint(-6, 1, (n,), generator=g).float())
+        gr[::97] = 0.0
+        gr *= 3.0 / step
+        gd = gr.cuda()
+        clip_ptr = None
+        g_eff = gr * gscale
+        if clip:
+            # clip acts on the gradient the optimiser sees (already averaged over ranks)
+            L.check(lib.cilrs_scale(L.ptr(gd), n, None, gscale, stream()))
+            L.check(lib.cilrs_grad_sqnorm(L.ptr(gd), n, max_norm, L.ptr(scr), L.ptr(clip_out),
+                                          stream()))
+            clip_ptr = L.ptr(clip_out)
+            p_ref.grad = g_eff.clone()
+            tn = torch.nn.utils.clip_grad_norm_([p_ref], max_norm)
+            L.check(lib.cilrs_adam_step(L.ptr(pd), L.ptr(gd), L.ptr(m), L.ptr(v), n, lr, b1, b2,
+                                        eps, wd, step, clip_ptr, 1.0, stream()))
+            torch.cuda.synchronize()
+            assert abs(float(clip_out[0]) - float(tn)) <= 1e-5 * float(tn)
+            assert abs(float(clip_out[1]) - min(1.0, max_norm / (float(tn) + 1e-6))) <= 1e-6
+        else:
+            p_ref.grad = g_eff.clone()
+            L.check(lib.cilrs_adam_step(L.ptr(pd), L.ptr(gd), L.ptr(m), L.ptr(v), n, lr, b1, b2,
+                                        eps, wd, step, None, gscale, stream()))
+        opt.step()
+        torch.cuda.synchronize()
+        st = opt.state[p_ref]
+        assert (pd.cpu() - p_ref.detach()).abs().max() <= 1e-6, step
+        assert (m.cpu() - st["exp_avg"]).abs().max() <= 1e-6 * max(1.0, float(st["exp_avg"].abs().max()))
+        assert (v.cpu() - st["exp_avg_sq"]).abs().max() <= 1e-6 * max(1.0, float(st["exp_avg_sq"].abs().max()))
+    # and the trajectory really moved by more than the tolerance
+    assert (p_ref.detach() - p0).abs().max() >= 4 * lr
