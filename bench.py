@@ -67,10 +67,11 @@ def cpu_baseline(batch_cpu, state0, gpu_out, gpu_loss1, steps=3, forwards=50):
     after 5 warm-ups."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import cilrs_oracle as O
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
+    from cilrs_mi355 import hostinfo
+    # every core this job may keep busy: the affinity mask of a shared GPU box lists the whole
+    # machine, the job's CPU share is 16 cores per GPU (hostinfo.py) -- more threads than that
+    # oversubscribe the share and run an order of magnitude slower
+    cores = hostinfo.usable_cores()
     torch.set_num_threads(cores)
     imgs, spds, cmds, tgts = batch_cpu
     batch = imgs.size(0)
@@ -98,7 +99,7 @@ def cpu_baseline(batch_cpu, state0, gpu_out, gpu_loss1, steps=3, forwards=50):
     base = dict(value=round(batch * steps / dt, 2), unit="frames/s", cores=cores, kind="port",
                 sample=f"{steps} Config-A train steps at B={batch} on the GPU run's own batch and "
                        f"initial weights (after the parity step as warm-up), "
-                       f"torch.set_num_threads({cores}) = every core this process may use; "
+                       f"torch.set_num_threads({cores}) [{hostinfo.describe()}]; "
                        f"infer = mean of {forwards} B=1 eval forwards after 5 warm-ups",
                 infer_ms=round(infer_ms, 3))
     return base, err_out, err_loss
@@ -119,7 +120,7 @@ def launch_ranks(n, argv):
            os.path.abspath(__file__)] + argv
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    env.setdefault("OMP_NUM_THREADS", "2")
     print(f"[bench] starting {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
     line_out = None

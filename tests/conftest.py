@@ -36,3 +36,17 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _cpu_threads_fit_the_box():
+    """The CPU oracle runs inside the GPU tests: size torch's thread pool to the cores this job
+    may really use (cilrs_mi355/hostinfo.py) -- the affinity mask of a shared GPU box is the whole
+    machine and oversubscribing the job's CPU share makes every oracle step crawl."""
+    try:
+        import torch
+        from cilrs_mi355.hostinfo import usable_cores
+        torch.set_num_threads(usable_cores())
+    except Exception:
+        pass
+    yield

@@ -125,8 +125,15 @@ def _fp64_grads(ocfg, imgs, spds, cmds, tgts):
 # Fraction of a tensor's elements allowed to differ by more than 2e-5 after k Adam steps, and the
 # count allowed in tensors too small for a fraction to mean anything.  Measured on MI355X with
 # tools/param_outliers.py (profiles/r02_param_outliers.log): see OUTLIER_FRAC below.
-OUTLIER_FRAC = {1: 2e-4, 2: 2e-3, 3: 5e-3}
-OUTLIER_FLOOR = 6
+#   one step from identical state (Adam's step-1 update is lr*sign(g), so only sign flips of
+#   near-zero gradients show): 4.0e-4 of all elements at B=8, worst tensor 2.0e-3, at most 2
+#   elements in any tensor below 4096 elements -> gate 1e-2 (5x the worst tensor), floor 8;
+#   free-running trajectories (every later update depends on the RATIO of noisy gradients, and
+#   the parameters already differ): step 2 up to 7.6e-2 / 29, step 3 up to 0.24 / 77 per tensor
+#   -> gates 0.25 / 0.6 -- by then only the hard bound is a real check, which is why the
+#   optimiser's arithmetic is pinned separately (re-synchronised step below, Adam op test)
+OUTLIER_FRAC = {1: 1e-2, 2: 0.25, 3: 0.6}
+OUTLIER_FLOOR = {1: 8, 2: 64, 3: 160}
 
 
 def _close_params(mine, want, lr, steps):
@@ -135,8 +142,8 @@ def _close_params(mine, want, lr, steps):
     err = (mine - want).abs()
     assert float(err.max()) <= 2.2 * lr * steps + 1e-6
     nbad = int((err > 2e-5).sum())
-    assert nbad <= max(OUTLIER_FLOOR, int(OUTLIER_FRAC[min(steps, 3)] * err.numel())), \
-        (nbad, err.numel())
+    k = min(steps, 3)
+    assert nbad <= max(OUTLIER_FLOOR[k], int(OUTLIER_FRAC[k] * err.numel())), (nbad, err.numel())
 
 
 @pytest.mark.parametrize("cfg_name", ["A", "B"])
@@ -215,12 +222,32 @@ def test_train_steps_golden_and_oracle(golden_dir, cfg_name):
                 assert abs(float(mine.double().norm()) - chk["l2"]) <= 1e-4 * max(1.0, chk["l2"])
     # BN running statistics after 3 steps
     sd = m.state_dict()
+    bn_sums = {name: float(sd[name].double().sum()) for name in ref["buffers"]
+               if not name.endswith("num_batches_tracked")}
+    nbt = {name: int(sd[name]) for name in ref["buffers"] if name.endswith("num_batches_tracked")}
+    # ---- one more step from RE-SYNCHRONISED state: the oracle's parameters, BN buffers and Adam
+    # moments (step count 3, non-zero exp_avg / exp_avg_sq) are loaded into the HIP trainer, so
+    # this step's update exercises the bias corrections, betas and weight decay with history --
+    # and, starting from identical state, must agree as closely as a first step does
+    from cilrs_mi355 import checkpoint
+    m.load_state_dict(orc.state_dict(), strict=True)
+    checkpoint.load_optimizer_state_dict(tr, oopt.state_dict())
+    assert tr.step_count == 3
+    imgs, spds, cmds, tgts = O.synthetic_batch(8, seed=ref["seeds"][0] + 1000)[:4]
+    tr.train_step(*to_dev(imgs, spds, cmds, tgts))
+    got = tr.losses()
+    old, _ = O.train_step(orc, oopt, ocfg, imgs, spds, cmds, tgts)
+    for k, v in old.items():
+        assert abs(got[k] - v) <= 1e-4 * max(1.0, abs(v)), ("resync", k, got[k], v)
+    pv = dict(m.named_parameters())
+    for n, p in orc.named_parameters():
+        _close_params(pv[n].detach().cpu(), p.detach(), cfg.lr, 1)
     for name, chk in ref["buffers"].items():
         if name.endswith("num_batches_tracked"):
-            assert int(sd[name]) == 3
+            assert nbt[name] == 3
         else:
             # three steps in, parameters differ by Adam's sign ambiguity (see _close_params)
-            assert abs(float(sd[name].double().sum()) - chk["sum"]) <= 5e-3 * max(1.0, abs(chk["sum"]))
+            assert abs(bn_sums[name] - chk["sum"]) <= 5e-3 * max(1.0, abs(chk["sum"]))
 
 
 def test_autograd_path_matches_fused_step():
@@ -626,7 +653,8 @@ def test_train_step_b128_vs_oracle(cfg_name):
     size every convolution runs the plan the benchmark times (other tiles, split-K factors and
     K-slab counts than the B = 8 fixtures)."""
     from cilrs_mi355 import Trainer
-    torch.set_num_threads(max(1, len(os.sched_getaffinity(0))))
+    from cilrs_mi355.hostinfo import usable_cores
+    torch.set_num_threads(usable_cores())
     cfg, ocfg = _cfgs()[cfg_name]
     B = 128
     imgs, spds, cmds, tgts = O.synthetic_batch(B, seed=4242)[:4]

@@ -357,7 +357,8 @@ def test_conv_auto_plan_at_benchmark_batch(shape):
     lib = L.lib()
     N = 128
     H, W, Cin, Cout, k, s, p = shape
-    torch.set_num_threads(max(1, len(__import__("os").sched_getaffinity(0))))
+    from cilrs_mi355.hostinfo import usable_cores
+    torch.set_num_threads(usable_cores())
     g = torch.Generator().manual_seed(100 + Cin + Cout + k)
     x = torch.randn(N, Cin, H, W, generator=g, requires_grad=True)
     w = (torch.randn(Cout, Cin, k, k, generator=g) / (k * k * Cin) ** 0.5).requires_grad_(True)

@@ -51,10 +51,10 @@ def run(B, cfg, ocfg, steps, seeds, tag, hw=(88, 200)):
 
 
 if __name__ == "__main__":
-    torch.set_num_threads(len(os.sched_getaffinity(0)))
+    from cilrs_mi355.hostinfo import describe, usable_cores
+    torch.set_num_threads(usable_cores())
+    print(describe(), flush=True)
     cb = TrainConfig(**{**CONFIG_B.__dict__, "dropout": 0.0})
-    run(8, CONFIG_A, O.CONFIG_A, 3, [11, 12, 13], "cfgA")
-    run(8, cb, O.CONFIG_B, 3, [11, 12, 13], "cfgB")
     run(4, CONFIG_A, O.CONFIG_A, 1, [1], "cfgA")
     run(3, CONFIG_A, O.CONFIG_A, 1, [5], "cfgA 96x160", hw=(96, 160))
     run(5, CONFIG_A, O.CONFIG_A, 1, [6], "cfgA 64x64", hw=(64, 64))
