@@ -472,6 +472,58 @@ def main():
         out["infer_device_us"]["total"] = round(sum(v["ms"] for v in t1.values()) / 10 * 1e3, 1)
         model.train()
 
+        # ---- BASELINE configs[3] on this GPU's share: ResNet-50 variant, 176x400 frames, trunk
+        # on the bf16 matrix pipe (BatchNorm folded), batched inference at 64 frames per call.
+        # The reference has no such model; random-init weights, synthetic uint8 frames resident
+        # in HBM.  Roofline: algorithmic conv FLOPs and bytes of the bf16 trunk per forward.
+        from cilrs_mi355 import CILRSResNet50
+        torch.manual_seed(0)
+        m50 = CILRSResNet50(4, 0.0).to(dev).eval()
+        eng50 = m50.engine()
+        b50 = 64
+        u50 = torch.randint(0, 256, (b50, 176, 400, 3), dtype=torch.uint8, device=dev)
+        s50 = torch.rand(b50, device=dev)
+        c50 = torch.randint(0, 4, (b50,), device=dev)
+        for _ in range(3):
+            eng50.run_forward_u8(u50, s50, c50, half="bf16")
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(10):
+            eng50.run_forward_u8(u50, s50, c50, half="bf16")
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t1) / 10
+        pl50 = eng50.plan(b50, 176, 400)
+        pl50.profile_reset()
+        pl50.profile(True)
+        for _ in range(3):
+            eng50.run_forward_u8(u50, s50, c50, half="bf16")
+        torch.cuda.synchronize(dev)
+        t50 = pl50.profile_table()
+        pl50.profile(False)
+        conv = [v for k, v in t50.items() if k.startswith("conv_fwd") and k != "conv_fwd.stem"]
+        cms = sum(v["ms"] for v in conv) / 3
+        cfl = sum(v["flops"] for v in conv) / 3
+        cby = sum(v["bytes"] for v in conv) / 3
+        ncalls = sum(v["calls"] for v in conv) // 3
+        tf, gbs = cfl / max(cms, 1e-9) / 1e9, cby / max(cms, 1e-9) / 1e6
+        out["resnet50_bf16"] = {
+            "workload": "CILRS ResNet-50 variant eval forward, 176x400 RGB, B=64, bf16 trunk "
+                        "(fp32 stem + heads), random-init weights, synthetic frames",
+            "frames_per_s": round(b50 / dt, 1), "ms_per_batch": round(dt * 1e3, 3),
+            "dtype": "bf16", "n_gpus": 1,
+            "roofline": {"kernel": "conv_f16_kernel<bf16> (52 launches per forward)",
+                         "bound": "mfma" if tf / 2500.0 >= gbs / PEAK_HBM_GBS else "hbm",
+                         "achieved_tflops": round(tf, 1), "peak_tflops": 2500.0,
+                         "frac_mfma": round(tf / 2500.0, 4),
+                         "achieved_gbs": round(gbs, 1), "peak_gbs": PEAK_HBM_GBS,
+                         "frac_hbm": round(gbs / PEAK_HBM_GBS, 4),
+                         "launches_per_forward": ncalls,
+                         "avg_launch_us": round(cms / max(ncalls, 1) * 1e3, 2),
+                         "gflop_per_frame_trunk": round(cfl / b50 / 1e9, 3)},
+            "device_ms_by_layer": {k: round(v["ms"] / 3, 4) for k, v in sorted(t50.items())}}
+        del m50, eng50, pl50, u50
+        torch.cuda.empty_cache()
+
     if want_parity:
         log("CPU oracle: parity of this run's batch + host baseline")
         batch_cpu = [t.cpu() for t in batch]

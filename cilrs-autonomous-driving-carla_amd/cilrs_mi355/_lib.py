@@ -40,7 +40,19 @@ SIGNATURES = {
                                C.POINTER(i32), C.POINTER(i32)]),
     "cilrs_bn_info": (i32, [i32, C.c_char_p, i32, C.POINTER(i32), C.POINTER(sz), C.POINTER(sz)]),
     "cilrs_bn_arena_floats": (sz, []),
+    "cilrs_num_variants": (i32, []),
+    "cilrs_variant_num_params": (i32, [i32]),
+    "cilrs_variant_num_bn": (i32, [i32]),
+    "cilrs_variant_param_arena_floats": (sz, [i32]),
+    "cilrs_variant_param_count": (sz, [i32]),
+    "cilrs_variant_bn_arena_floats": (sz, [i32]),
+    "cilrs_variant_feature_width": (i32, [i32]),
+    "cilrs_variant_param_info": (i32, [i32, i32, C.c_char_p, i32, C.POINTER(sz), C.POINTER(sz),
+                                       C.POINTER(i32), C.POINTER(i32)]),
+    "cilrs_variant_bn_info": (i32, [i32, i32, C.c_char_p, i32, C.POINTER(i32), C.POINTER(sz),
+                                    C.POINTER(sz)]),
     "cilrs_net_create": (i32, [i32, i32, i32, C.POINTER(vp)]),
+    "cilrs_net_create_variant": (i32, [i32, i32, i32, i32, C.POINTER(vp)]),
     "cilrs_net_destroy": (None, [vp]),
     "cilrs_net_workspace_bytes": (sz, [vp]),
     "cilrs_net_status_offset": (sz, [vp]),
@@ -53,6 +65,8 @@ SIGNATURES = {
     "cilrs_net_forward_u8_f16": (i32, [vp, C.POINTER(Buffers), vp, vp, vp, vp, vp, vp]),
     "cilrs_net_forward_u8_f16_graph": (i32, [vp, C.POINTER(Buffers), vp, vp, vp, vp, vp, vp]),
     "cilrs_net_forward_u8_graph": (i32, [vp, C.POINTER(Buffers), vp, vp, vp, vp, vp, vp]),
+    "cilrs_net_forward_u8_bf16": (i32, [vp, C.POINTER(Buffers), vp, vp, vp, vp, vp, vp]),
+    "cilrs_net_forward_u8_bf16_graph": (i32, [vp, C.POINTER(Buffers), vp, vp, vp, vp, vp, vp]),
     "cilrs_loss_fwd_bwd": (i32, [vp, vp, vp, vp, i32, i32, c_float_p, f32, vp, vp, vp, vp]),
     "cilrs_net_backward": (i32, [vp, C.POINTER(Buffers), vp, vp, i32, i32, vp]),
     "cilrs_segment_range": (i32, [i32, C.POINTER(sz), C.POINTER(sz)]),

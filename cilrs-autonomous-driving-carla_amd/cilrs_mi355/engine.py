@@ -25,21 +25,24 @@ from . import _lib as L
 SEG_NAMES = ("heads", "layer4", "layer3", "layer2", "layer1", "stem")
 
 
-def _layout():
+def _layout(variant=0):
+    """(parameter layout, BatchNorm layout) of architecture `variant` (0: the reference's
+    ResNet-34 network; 1: the ResNet-50 variant of BASELINE.json configs[3])."""
     lib = L.lib()
     params = []
     name = C.create_string_buffer(256)
-    for i in range(lib.cilrs_num_params()):
+    for i in range(lib.cilrs_variant_num_params(variant)):
         off, numel, ndim = L.sz(), L.sz(), L.i32()
         shape = (L.i32 * 4)()
-        L.check(lib.cilrs_param_info(i, name, 256, C.byref(off), C.byref(numel), C.byref(ndim),
-                                     shape))
+        L.check(lib.cilrs_variant_param_info(variant, i, name, 256, C.byref(off), C.byref(numel),
+                                             C.byref(ndim), shape))
         params.append((name.value.decode(), off.value, numel.value,
                        tuple(shape[k] for k in range(ndim.value))))
     bns = []
-    for j in range(lib.cilrs_num_bn()):
+    for j in range(lib.cilrs_variant_num_bn(variant)):
         ch, rm, rv = L.i32(), L.sz(), L.sz()
-        L.check(lib.cilrs_bn_info(j, name, 256, C.byref(ch), C.byref(rm), C.byref(rv)))
+        L.check(lib.cilrs_variant_bn_info(variant, j, name, 256, C.byref(ch), C.byref(rm),
+                                          C.byref(rv)))
         bns.append((name.value.decode(), ch.value, rm.value, rv.value))
     return params, bns
 
@@ -66,10 +69,10 @@ def _arena_view(arena, off, numel, shape):
 class Plan:
     """cilrs_net for one (batch, H, W) + its workspace."""
 
-    def __init__(self, device, batch, h, w):
+    def __init__(self, device, batch, h, w, variant=0):
         lib = L.lib()
         handle = L.vp()
-        L.check(lib.cilrs_net_create(batch, h, w, C.byref(handle)))
+        L.check(lib.cilrs_net_create_variant(variant, batch, h, w, C.byref(handle)))
         self.handle = handle
         self.batch, self.h, self.w = batch, h, w
         nbytes = lib.cilrs_net_workspace_bytes(handle)
@@ -119,8 +122,9 @@ class Plan:
 
 
 class Engine:
-    def __init__(self, module):
+    def __init__(self, module, variant=0):
         lib = L.lib()                                    # raises if the extension is missing
+        self.variant = variant
         named = list(module.named_parameters())
         if not named:
             raise RuntimeError("CILRS has no parameters")
@@ -131,16 +135,17 @@ class Engine:
                 "engine has no CPU fallback")
         self.device = device
         self.module = module
-        self.params_layout, self.bn_layout = _layout()
+        self.params_layout, self.bn_layout = _layout(variant)
         names = [n for n, _ in named]
         want = [p[0] for p in self.params_layout]
         if names != want:
             raise RuntimeError("module parameter names differ from the engine layout")
-        n_arena = lib.cilrs_param_arena_floats()
+        n_arena = lib.cilrs_variant_param_arena_floats(variant)
         self.n_arena = n_arena
         self.params = torch.zeros(n_arena, dtype=torch.float32, device=device)
         self.grads = torch.zeros(n_arena, dtype=torch.float32, device=device)
-        self.bn = torch.zeros(lib.cilrs_bn_arena_floats(), dtype=torch.float32, device=device)
+        self.bn = torch.zeros(lib.cilrs_variant_bn_arena_floats(variant), dtype=torch.float32,
+                              device=device)
         self.nbt = torch.zeros(len(self.bn_layout), dtype=torch.int64, device=device)
         self.param_views, self.grad_views = [], []
         with torch.no_grad():
@@ -185,7 +190,7 @@ class Engine:
         key = (batch, h, w)
         pl = self.plans.get(key)
         if pl is None:
-            pl = Plan(self.device, batch, h, w)
+            pl = Plan(self.device, batch, h, w, self.variant)
             self.plans[key] = pl
             self.bufs[key] = L.Buffers(self.params.data_ptr(), self.grads.data_ptr(),
                                        self.bn.data_ptr(), self.nbt.data_ptr(),
@@ -237,8 +242,9 @@ class Engine:
     def run_forward_u8(self, frames_u8, speed, command, out=None, graph=False, half=False):
         """uint8 RGB HWC frames [B,H,W,3] -> eval forward with fused preprocessing.  With
         graph=True the launch sequence is replayed from a cached hipGraph (all tensors must keep
-        their addresses; the current stream must not be the default stream).  half=True runs the
-        BasicBlock trunk in fp16 (BatchNorm folded, fp32 accumulation): batched serving."""
+        their addresses; the current stream must not be the default stream).  half=True / "f16"
+        runs the trunk in fp16, half="bf16" in bf16 (BatchNorm folded into 16-bit weights, fp32
+        accumulation): batched serving."""
         if frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4 or frames_u8.size(3) != 3:
             raise RuntimeError("frames must be uint8 [B,H,W,3]")
         b = frames_u8.size(0)
@@ -250,9 +256,12 @@ class Engine:
         else:
             controls, pred_speed = out
         lib = L.lib()
-        fn = ((lib.cilrs_net_forward_u8_f16_graph if graph else lib.cilrs_net_forward_u8_f16)
-              if half else
-              (lib.cilrs_net_forward_u8_graph if graph else lib.cilrs_net_forward_u8))
+        if half == "bf16":
+            fn = lib.cilrs_net_forward_u8_bf16_graph if graph else lib.cilrs_net_forward_u8_bf16
+        elif half:
+            fn = lib.cilrs_net_forward_u8_f16_graph if graph else lib.cilrs_net_forward_u8_f16
+        else:
+            fn = lib.cilrs_net_forward_u8_graph if graph else lib.cilrs_net_forward_u8
         L.check(fn(pl.handle, C.byref(self.bufs[(pl.batch, pl.h, pl.w)]), L.ptr(frames_u8),
                    L.ptr(speed.contiguous()), L.ptr(command.contiguous()), L.ptr(controls),
                    L.ptr(pred_speed), self._stream()))

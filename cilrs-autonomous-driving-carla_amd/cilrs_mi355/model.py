@@ -41,6 +41,33 @@ class BasicBlock(_NoEagerForward):
         self.stride = stride
 
 
+class Bottleneck(_NoEagerForward):
+    """Parameter container with torchvision Bottleneck's attribute names (ResNet-50 variant)."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, 1, 0, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)      # stride on the 3x3
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, 1, 0, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+
+def _make_bottleneck_layer(inplanes, planes, blocks, stride):
+    down = None
+    if stride != 1 or inplanes != planes * 4:
+        down = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, stride, bias=False),
+                             nn.BatchNorm2d(planes * 4))
+    layers = [Bottleneck(inplanes, planes, stride, down)]
+    layers += [Bottleneck(planes * 4, planes) for _ in range(1, blocks)]
+    return nn.Sequential(*layers)
+
+
 def _make_layer(inplanes, planes, blocks, stride):
     down = None
     if stride != 1 or inplanes != planes:
@@ -52,6 +79,19 @@ def _make_layer(inplanes, planes, blocks, stride):
 
 
 class CILRS(nn.Module):
+    VARIANT = 0          # engine architecture variant (include/cilrs_hip.h)
+    FEATURES = 512
+
+    def _trunk(self):
+        # ResNet-34 trunk, re-wrapped exactly as autonomous_drive.py:366-370 does, so indices
+        # 0,1,4,5,6,7 carry the parameters and 2,3,8,9 carry none.
+        return nn.Sequential(
+            nn.Conv2d(3, 64, 7, 2, 3, bias=False), nn.BatchNorm2d(64), nn.ReLU(inplace=True),
+            nn.MaxPool2d(3, 2, 1),
+            _make_layer(64, 64, 3, 1), _make_layer(64, 128, 4, 2),
+            _make_layer(128, 256, 6, 2), _make_layer(256, 512, 3, 2),
+            nn.AdaptiveAvgPool2d((1, 1)), nn.Flatten())
+
     def __init__(self, num_commands=4, dropout=0.0):
         super().__init__()
         if num_commands != 4:
@@ -60,25 +100,19 @@ class CILRS(nn.Module):
             raise ValueError("the HIP engine implements the reference's 4 command branches")
         self.num_commands = num_commands
         self.dropout = float(dropout)
-        # ResNet-34 trunk, re-wrapped exactly as autonomous_drive.py:366-370 does, so indices
-        # 0,1,4,5,6,7 carry the parameters and 2,3,8,9 carry none.
-        self.visual_encoder = nn.Sequential(
-            nn.Conv2d(3, 64, 7, 2, 3, bias=False), nn.BatchNorm2d(64), nn.ReLU(inplace=True),
-            nn.MaxPool2d(3, 2, 1),
-            _make_layer(64, 64, 3, 1), _make_layer(64, 128, 4, 2),
-            _make_layer(128, 256, 6, 2), _make_layer(256, 512, 3, 2),
-            nn.AdaptiveAvgPool2d((1, 1)), nn.Flatten())
+        self.visual_encoder = self._trunk()
+        feat = self.FEATURES
         self.speed_encoder = nn.Sequential(
             nn.Linear(1, 128), nn.ReLU(inplace=True), nn.Dropout(dropout),
             nn.Linear(128, 128), nn.ReLU(inplace=True))
         self.control_branches = nn.ModuleList([
             nn.Sequential(
-                nn.Linear(640, 256), nn.ReLU(inplace=True), nn.Dropout(dropout),
+                nn.Linear(feat + 128, 256), nn.ReLU(inplace=True), nn.Dropout(dropout),
                 nn.Linear(256, 256), nn.ReLU(inplace=True), nn.Dropout(dropout),
                 nn.Linear(256, 3))
             for _ in range(num_commands)])
         self.speed_predictor = nn.Sequential(
-            nn.Linear(512, 256), nn.ReLU(inplace=True), nn.Dropout(dropout),
+            nn.Linear(feat, 256), nn.ReLU(inplace=True), nn.Dropout(dropout),
             nn.Linear(256, 256), nn.ReLU(inplace=True),
             nn.Linear(256, 1))
         # torchvision.models.resnet34(pretrained=False) initialisation (:365)
@@ -98,7 +132,7 @@ class CILRS(nn.Module):
         """The HIP engine bound to this module's parameters (built on first use)."""
         eng = self._engine
         if eng is None or not eng.is_attached():
-            eng = Engine(self)
+            eng = Engine(self, self.VARIANT)
             self._engine = eng
         return eng
 
@@ -114,3 +148,29 @@ class CILRS(nn.Module):
             self._dropout_calls += 1
             seed = dropout_seed(torch.initial_seed(), self._dropout_calls, rank)
         return eng.forward(image, speed, command, self.training, p, seed)
+
+
+class CILRSResNet50(CILRS):
+    """BASELINE.json configs[3]: the same CILRS heads on a ResNet-50 trunk (torchvision-style
+    Bottleneck stacks [3,4,6,3], stride on the 3x3 convolution; 2048-d features, so the first
+    Linear of every branch is 2176 wide and the speed predictor's 2048 wide).  The reference has
+    no such model (model/autonomous_drive.py:365 is resnet34 only); state_dict keys follow the
+    same re-wrapping (visual_encoder.{4..7}.{blk}.{conv1,bn1,conv2,bn2,conv3,bn3,downsample}).
+    Inference only: eval-mode forward in fp32, or through Engine.run_forward_u8(half="bf16")
+    with the trunk on the bf16 matrix pipe."""
+    VARIANT = 1
+    FEATURES = 2048
+
+    def _trunk(self):
+        return nn.Sequential(
+            nn.Conv2d(3, 64, 7, 2, 3, bias=False), nn.BatchNorm2d(64), nn.ReLU(inplace=True),
+            nn.MaxPool2d(3, 2, 1),
+            _make_bottleneck_layer(64, 64, 3, 1), _make_bottleneck_layer(256, 128, 4, 2),
+            _make_bottleneck_layer(512, 256, 6, 2), _make_bottleneck_layer(1024, 512, 3, 2),
+            nn.AdaptiveAvgPool2d((1, 1)), nn.Flatten())
+
+    def forward(self, image, speed, command):
+        if self.training:
+            raise RuntimeError("CILRSResNet50 is an inference-only variant: call .eval() first "
+                               "(the HIP engine has no ResNet-50 training path)")
+        return super().forward(image, speed, command)

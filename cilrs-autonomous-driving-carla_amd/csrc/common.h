@@ -54,6 +54,16 @@ static inline size_t cdivz(size_t a, size_t b) { return (a + b - 1) / b; }
 //   * data gradient (dgrad)  dx[m][ci] = sum_{tap,co} dy[pix'(m,tap)][co] * W[co][flip(tap)][ci]
 //   * the 128..640-wide linear layers of the heads (1x1 "convs" over a [B,1,1,C] image)
 // Activations are NHWC, weights OHWI ([Cout][KH][KW][Cin], i.e. torch channels_last memory).
+// Up to four sub-problems run by ONE launch: the output-parity classes of a stride-2 data gradient.
+// They share x / w / y, the channel counts and the output tensor; each has its own enumerated
+// output grid, its own (at most four) filter taps and its own place in the output.
+struct ConvMulti {
+    int n;                 // 0 = a single problem (everything below unused)
+    int tile_begin[5];     // cumulative block count per class (class c owns [c], [c+1])
+    int Ho[4], Wo[4], out_h0[4], out_w0[4], ntaps[4];
+    int tap_dh[4][4], tap_dw[4][4], tap_w[4][4];
+};
+
 struct ConvArgs {
     const float* x;        // gathered operand: [N][H][W] pixels, x_ld floats apart, Cin used
     const float* w;        // weights (OHWI of the FORWARD conv)
@@ -96,6 +106,7 @@ struct ConvArgs {
                            // same tiles fed by LDS-DMA (tests/tuning)
     int force_splitk;      // 0 auto
     int splitk;            // set by the launcher
+    ConvMulti multi;       // set by launch_conv_dgrad (stride 2)
 };
 int launch_conv_igemm(const ConvArgs& a, hipStream_t s);
 // Data gradient of a forward conv (stride 1 or 2): dx[N,H,W,Cin] = dgrad(dy[N,Ho,Wo,Cout]) (+addend).
@@ -137,13 +148,15 @@ int launch_bn_train_fwd(const float* y, int M, int C, const float* gamma, const 
                         float* running_mean, float* running_var, long long* nbt, float momentum,
                         float eps, const float* residual, int relu, float* stats, float* partial,
                         float* z, int pre_nblk, hipStream_t s);
-// eval-mode scale/shift of up to 40 BatchNorm layers in one launch (offsets in floats)
+// eval-mode scale/shift of up to kMaxConvs BatchNorm layers in one launch (offsets in floats);
+// 36 layers in the ResNet-34 network, 53 in the ResNet-50 variant
+constexpr int kMaxConvs = 56;
 struct BnEvalTable {
     int n;
-    int C[40];
-    unsigned gamma[40], beta[40];      // into the parameter arena
-    unsigned rm[40], rv[40];           // into the BN buffer arena
-    unsigned stats[40];                // into the workspace (4*C floats: mean|rstd|w|b)
+    int C[kMaxConvs];
+    unsigned gamma[kMaxConvs], beta[kMaxConvs];      // into the parameter arena
+    unsigned rm[kMaxConvs], rv[kMaxConvs];           // into the BN buffer arena
+    unsigned stats[kMaxConvs];         // into the workspace (4*C floats: mean|rstd|w|b)
 };
 int launch_bn_eval_stats_all(const BnEvalTable& t, const float* params, const float* bn_running,
                              float* ws, float eps, hipStream_t s);
@@ -239,21 +252,23 @@ struct ConvF16Args {
     const cilrs_half* residual;   // [N][Ho][Wo][Cout] or NULL
     cilrs_half* y;                // [N][Ho][Wo][Cout]
     int N, H, W, Cin, Ho, Wo, Cout, K, stride, pad, relu;
+    int bf16;                     // 0: the 16-bit buffers hold fp16, 1: bf16
 };
 struct FoldF16Table {
     int n;
-    int cout[40];
-    unsigned krow[40];            // K*K*Cin
-    unsigned w[40];               // fp32 weights in the parameter arena
-    unsigned stats[40];           // eval-mode BN stats in the workspace (mean|rstd|scale|shift)
-    unsigned w16[40];             // halfs into the folded-weight arena
-    unsigned bias[40];            // floats into the folded-bias arena
+    int cout[kMaxConvs];
+    unsigned krow[kMaxConvs];     // K*K*Cin
+    unsigned w[kMaxConvs];        // fp32 weights in the parameter arena
+    unsigned stats[kMaxConvs];    // eval-mode BN stats in the workspace (mean|rstd|scale|shift)
+    unsigned w16[kMaxConvs];      // halfs into the folded-weight arena
+    unsigned bias[kMaxConvs];     // floats into the folded-bias arena
 };
 int launch_conv_f16(const ConvF16Args& a, hipStream_t s);
 int launch_fold_bn_f16(const FoldF16Table& t, const float* params, const float* ws, void* w16,
-                       float* bias, hipStream_t s);
-int launch_f32_to_f16(const float* x, void* y, size_t n, hipStream_t s);
-int launch_avgpool_f16(const void* x, float* out, int N, int HW, int C, int out_ld, hipStream_t s);
+                       float* bias, int bf16, hipStream_t s);
+int launch_f32_to_f16(const float* x, void* y, size_t n, int bf16, hipStream_t s);
+int launch_avgpool_f16(const void* x, float* out, int N, int HW, int C, int out_ld, int bf16,
+                       hipStream_t s);
 
 // grouped small GEMMs of the heads (heads_gemm.hip): mode 0 NT (linear forward), 1 NN (input
 // gradient), 2 TN (weight + bias gradient); one launch covers up to five chains

@@ -55,9 +55,12 @@ constexpr bool igemm_swz() { return DMA || (BM == 64 && BN == 64 && TAP_UNIFORM)
 template <int BM, int BN, bool TAP_UNIFORM, bool DMA>
 constexpr int igemm_min_blocks() { return (!DMA && BM == 64 && BN == 64 && TAP_UNIFORM) ? 5 : 2; }
 
-template <int BM, int BN, int WM, int WN, bool TAP_UNIFORM, int W_MODE, bool DMA>
+// MULTI: the launch covers a.multi.n sub-problems (parity classes of a stride-2 data gradient);
+// a block finds its class from its logical id and takes the class's output grid, taps and K
+// length from a.multi -- four short launches of 0.4 rounds each become one launch of whole rounds.
+template <int BM, int BN, int WM, int WN, bool TAP_UNIFORM, int W_MODE, bool DMA, bool MULTI = false>
 __global__ __launch_bounds__(256, (igemm_min_blocks<BM, BN, TAP_UNIFORM, DMA>()))
-void conv_igemm_kernel(const ConvArgs a, const int M, const int Krow, const int KT) {
+void conv_igemm_kernel(const ConvArgs a, const int M_, const int Krow, const int KT_) {
     static_assert(WM * WN == 4, "4 waves");
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -79,7 +82,23 @@ void conv_igemm_kernel(const ConvArgs a, const int M, const int Krow, const int 
     const int wm = wave / WN, wn = wave % WN;
 
     const int tilesN = a.Cout / BN;
-    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    int logical = xcd_remap(blockIdx.x, gridDim.x);
+    // geometry of this block's (sub-)problem
+    int cls = 0;
+    int P_Ho = a.Ho, P_Wo = a.Wo, P_h0 = a.out_h0, P_w0 = a.out_w0, P_ntaps = a.ntaps;
+    int M = M_, KT = KT_;
+    if constexpr (MULTI) {
+        while (cls + 1 < a.multi.n && logical >= a.multi.tile_begin[cls + 1]) ++cls;
+        logical -= a.multi.tile_begin[cls];
+        P_Ho = a.multi.Ho[cls]; P_Wo = a.multi.Wo[cls];
+        P_h0 = a.multi.out_h0[cls]; P_w0 = a.multi.out_w0[cls];
+        P_ntaps = a.multi.ntaps[cls];
+        M = a.N * P_Ho * P_Wo;
+        KT = P_ntaps * (a.Cin / BK);
+    }
+    auto tap_dh = [&](int t) { if constexpr (MULTI) return a.multi.tap_dh[cls][t]; else return a.tap_dh[t]; };
+    auto tap_dw = [&](int t) { if constexpr (MULTI) return a.multi.tap_dw[cls][t]; else return a.tap_dw[t]; };
+    auto tap_w = [&](int t) { if constexpr (MULTI) return a.multi.tap_w[cls][t]; else return a.tap_w[t]; };
     const int m0 = (logical / tilesN) * BM;
     const int n0 = (logical % tilesN) * BN;
 
@@ -100,20 +119,20 @@ void conv_igemm_kernel(const ConvArgs a, const int M, const int Krow, const int 
     long rowBase[A_PASSES];        // element offset of the row's base pixel (+ kql*4)
     unsigned rowMask[A_PASSES];    // uniform path: bit t = tap t inside the image
     int rowH[A_PASSES], rowW[A_PASSES];   // generic path only
-    const int HoWo = a.Ho * a.Wo;
+    const int HoWo = P_Ho * P_Wo;
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i) {
         const int m = m0 + r0 + 32 * i;
         rowMask[i] = 0u; rowBase[i] = 0; rowH[i] = -(1 << 20); rowW[i] = 0;
         if (m < M) {
             const int n = m / HoWo, rem = m - n * HoWo;
-            const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
+            const int oh = rem / P_Wo, ow = rem - oh * P_Wo;
             const int hb = oh * a.stride - a.pad, wb = ow * a.stride - a.pad;
             rowBase[i] = ((long)(n * a.H + hb) * a.W + wb) * a.x_ld + kql * 4;
             if constexpr (TAP_UNIFORM) {
                 unsigned msk = 0u;
-                for (int t = 0; t < a.ntaps; ++t) {
-                    const int h = hb + a.tap_dh[t], w = wb + a.tap_dw[t];
+                for (int t = 0; t < P_ntaps; ++t) {
+                    const int h = hb + tap_dh(t), w = wb + tap_dw(t);
                     if (h >= 0 && w >= 0 && h < a.H && w < a.W) msk |= 1u << t;
                 }
                 rowMask[i] = msk;
@@ -150,9 +169,9 @@ void conv_igemm_kernel(const ConvArgs a, const int M, const int Krow, const int 
         for (int i = 0; i < A_PASSES; ++i) rowOff[i] = (unsigned)(rowBase[i] * 4);
 #pragma unroll
         for (int i = 0; i < B_PASSES; ++i) wOff[i] = (unsigned)(wBase[i] * 4);
-        if (lane < a.ntaps) {
-            tapA_v = (a.tap_dh[lane] * a.W + a.tap_dw[lane]) * a.x_ld * 4;
-            tapB_v = a.tap_w[lane] * (W_MODE == 0 ? a.Cin : a.w_cin) * 4;
+        if (lane < P_ntaps) {
+            tapA_v = (tap_dh(lane) * a.W + tap_dw(lane)) * a.x_ld * 4;
+            tapB_v = tap_w(lane) * (W_MODE == 0 ? a.Cin : a.w_cin) * 4;
         }
     }
 
@@ -207,7 +226,7 @@ void conv_igemm_kernel(const ConvArgs a, const int M, const int Krow, const int 
                 rb[i] = __builtin_bit_cast(
                     f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)(wOff[i] + koff), 0, 0));
         } else if constexpr (TAP_UNIFORM) {
-            const long toff = ((long)a.tap_dh[ld_tap] * a.W + a.tap_dw[ld_tap]) * a.x_ld +
+            const long toff = ((long)tap_dh(ld_tap) * a.W + tap_dw(ld_tap)) * a.x_ld +
                               ld_c * BK;
 #pragma unroll
             for (int i = 0; i < A_PASSES; ++i) {
@@ -216,8 +235,8 @@ void conv_igemm_kernel(const ConvArgs a, const int M, const int Krow, const int 
                 put_a(ra, i, p);
             }
             long koff;
-            if constexpr (W_MODE == 0) koff = (long)a.tap_w[ld_tap] * a.Cin + ld_c * BK;
-            else koff = (long)(ld_c * BK) * wrow + (long)a.tap_w[ld_tap] * a.w_cin;
+            if constexpr (W_MODE == 0) koff = (long)tap_w(ld_tap) * a.Cin + ld_c * BK;
+            else koff = (long)(ld_c * BK) * wrow + (long)tap_w(ld_tap) * a.w_cin;
 #pragma unroll
             for (int i = 0; i < B_PASSES; ++i) put_b(rb, i, a.w + (wBase[i] + koff));
         } else {
@@ -490,8 +509,8 @@ void conv_igemm_kernel(const ConvArgs a, const int M, const int Krow, const int 
     // Optional operands are fetched as 16 independent loads per tile (clamped row, no per-element
     // branch) so their latency overlaps instead of serialising.
     const bool partial = a.splitk > 1 && !inkernel_reduce;
-    const bool dense = (a.out_sh == 1) && (a.out_sw == 1) && (a.out_H == a.Ho) &&
-                       (a.out_W == a.Wo);
+    const bool dense = (a.out_sh == 1) && (a.out_sw == 1) && (a.out_H == P_Ho) &&
+                       (a.out_W == P_Wo);
     float* yout = partial ? a.y + (size_t)blockIdx.z * M * a.y_ld : a.y;
     // fused BatchNorm-backward reductions of the layer this data gradient feeds: per channel
     // sum(g) and sum(g * xhat), g = dz * (z > 0), xhat = (y - mean) * rstd
@@ -513,9 +532,9 @@ void conv_igemm_kernel(const ConvArgs a, const int M, const int Krow, const int 
                     pix[r] = m;
                 } else {
                     const int n = m / HoWo, rem = m - n * HoWo;
-                    const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
-                    pix[r] = (n * a.out_H + oh * a.out_sh + a.out_h0) * a.out_W +
-                             ow * a.out_sw + a.out_w0;
+                    const int oh = rem / P_Wo, ow = rem - oh * P_Wo;
+                    pix[r] = (n * a.out_H + oh * a.out_sh + P_h0) * a.out_W +
+                             ow * a.out_sw + P_w0;
                 }
             }
             float v[16];
@@ -1026,6 +1045,81 @@ int launch_conv_dgrad(const DgradArgs& d, hipStream_t s) {
     }
     // stride 2: dx pixel (hi, wi) = (2*oh + ph, 2*ow + pw) only sees taps kh with
     // (ph + pad - kh) even, reading dy row oh + (ph + pad - kh)/2
+    //
+    // Default: ALL FOUR parity classes in one launch (a class alone is 0.4 rounds of blocks with a
+    // quarter of the K length; launched separately they ran at 52-61 TF).  Classes are ordered by
+    // K length, longest first; a class no tap reaches (1x1 / s2) still gets blocks: with zero
+    // K-tiles they write the addend (or zeros) through the ordinary epilogue.
+    const bool fuse = d.force_cfg < 0 && d.force_splitk <= 0 && (d.Cout % BK) == 0 &&
+                      (d.Cin % 64) == 0;
+    if (fuse) {
+        ConvArgs c = a;
+        c.stride = 1; c.pad = 0;
+        c.out_H = d.H; c.out_W = d.W; c.out_sh = 2; c.out_sw = 2; c.out_h0 = c.out_w0 = 0;
+        c.Ho = (d.H + 1) / 2; c.Wo = (d.W + 1) / 2;          // class (0,0): never empty
+        c.splitk = 1; c.scratch = nullptr; c.tile_counters = nullptr;
+        struct Cls { int ph, pw, nt, Ho, Wo; int dh[4], dw[4], tw[4]; } cl[4];
+        int ncl = 0;
+        for (int ph = 0; ph < 2; ++ph)
+            for (int pw = 0; pw < 2; ++pw) {
+                Cls k;
+                k.ph = ph; k.pw = pw; k.nt = 0;
+                k.Ho = (d.H - ph + 1) / 2; k.Wo = (d.W - pw + 1) / 2;
+                if (k.Ho <= 0 || k.Wo <= 0) continue;
+                for (int kh = 0; kh < d.K; ++kh) {
+                    if ((ph + d.pad - kh) & 1) continue;
+                    for (int kw = 0; kw < d.K; ++kw) {
+                        if ((pw + d.pad - kw) & 1) continue;
+                        CILRS_CHECK(k.nt < 4, "dgrad: more than 4 taps in a parity class");
+                        k.dh[k.nt] = (ph + d.pad - kh) / 2;
+                        k.dw[k.nt] = (pw + d.pad - kw) / 2;
+                        k.tw[k.nt] = kh * d.K + kw;
+                        ++k.nt;
+                    }
+                }
+                cl[ncl++] = k;
+            }
+        for (int i = 1; i < ncl; ++i)                        // longest K first (stable)
+            for (int j = i; j > 0 && cl[j].nt > cl[j - 1].nt; --j) {
+                const Cls t = cl[j]; cl[j] = cl[j - 1]; cl[j - 1] = t;
+            }
+        ConvMulti& mu = c.multi;
+        memset(&mu, 0, sizeof(mu));
+        mu.n = ncl;
+        const int tilesN = c.Cout / 64;
+        int total = 0;
+        for (int i = 0; i < ncl; ++i) {
+            mu.tile_begin[i] = total;
+            total += cdiv(c.N * cl[i].Ho * cl[i].Wo, 64) * tilesN;
+            mu.Ho[i] = cl[i].Ho; mu.Wo[i] = cl[i].Wo;
+            mu.out_h0[i] = cl[i].ph; mu.out_w0[i] = cl[i].pw; mu.ntaps[i] = cl[i].nt;
+            for (int t = 0; t < cl[i].nt; ++t) {
+                mu.tap_dh[i][t] = cl[i].dh[t]; mu.tap_dw[i][t] = cl[i].dw[t];
+                mu.tap_w[i][t] = cl[i].tw[t];
+            }
+        }
+        for (int i = ncl; i < 5; ++i) mu.tile_begin[i] = total;
+        CILRS_CHECK((size_t)c.N * c.H * c.W * c.x_ld * sizeof(float) < (1ull << 32) &&
+                        (size_t)c.Cin * c.KH * c.KW * c.w_cin * sizeof(float) < (1ull << 32),
+                    "conv_dgrad: tensor larger than 4 GB");
+        CILRS_CHECK(((uintptr_t)c.x & 15) == 0 && ((uintptr_t)c.w & 15) == 0 &&
+                        ((uintptr_t)c.y & 15) == 0 && c.x_ld % 4 == 0 && c.y_ld % 4 == 0 &&
+                        c.w_cin % 4 == 0,
+                    "conv_dgrad: operands must be 16-byte aligned");
+        constexpr size_t lds = (size_t)(2 * 64 * BK + 2 * BK * 64) * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            CILRS_HIP(hipFuncSetAttribute(
+                reinterpret_cast<const void*>(
+                    &conv_igemm_kernel<64, 64, 2, 2, true, 1, false, true>),
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+        conv_igemm_kernel<64, 64, 2, 2, true, 1, false, true>
+            <<<dim3(total, 1, 1), 256, lds, s>>>(c, 0, c.KH * c.KW * c.Cin, 0);
+        CILRS_LAUNCH_CHECK();
+        return 0;
+    }
     for (int ph = 0; ph < 2; ++ph)
         for (int pw = 0; pw < 2; ++pw) {
             ConvArgs c = a;

@@ -39,10 +39,18 @@ namespace {
 struct ParamT { std::string name; size_t off, numel; int ndim; int shape[4]; };
 struct BnT { std::string prefix; int C; size_t gamma, beta, rm, rv; };
 struct ConvT { int cin, cout, k, stride, pad; size_t w; int bn; int group; };
-struct BlockT { int conv1, conv2, down; };
+struct BlockT { int conv1, conv2, conv3, down; };   // conv3 = -1: BasicBlock; else Bottleneck
 struct LinT { int in, out; size_t w, b; };
 
+// variant 0: the reference's network -- ResNet-34 trunk (BasicBlock [3,4,6,3]), 512-d features
+//            (model/autonomous_drive.py:365-370)
+// variant 1: BASELINE.json configs[3], "ResNet-50 backbone variant": Bottleneck [3,4,6,3] with the
+//            stride on the 3x3 convolution (torchvision's ResNet-50 v1.5), 2048-d features into the
+//            same heads.  The reference has no such model; parity is against the build's own CPU
+//            restatement (oracle/resnet50_oracle.py).  Inference only.
 struct Arch {
+    int variant = 0;
+    int feat = 512;                     // trunk feature width (avg-pool output)
     std::vector<ParamT> params;
     std::vector<BnT> bns;
     std::vector<ConvT> convs;           // convs[0] = stem
@@ -93,12 +101,13 @@ struct Arch {
         return l;
     }
 
-    Arch() {
+    explicit Arch(int variant_) : variant(variant_) {
         const size_t stem_begin = arena_floats;
         add_conv("visual_encoder.0.weight", "visual_encoder.1", 3, 64, 7, 2, 3, 0);
         size_t layer_begin[5];
         const int nblk[4] = {3, 4, 6, 3};
         const int width[4] = {64, 128, 256, 512};
+        const int expansion = variant == 1 ? 4 : 1;
         int inpl = 64;
         for (int L = 0; L < 4; ++L) {
             layer_begin[L] = arena_floats;
@@ -106,29 +115,41 @@ struct Arch {
                 const std::string p =
                     "visual_encoder." + std::to_string(4 + L) + "." + std::to_string(b);
                 const int stride = (b == 0 && L > 0) ? 2 : 1;
+                const int outpl = width[L] * expansion;
                 BlockT blk;
-                blk.conv1 = add_conv(p + ".conv1.weight", p + ".bn1", inpl, width[L], 3, stride,
-                                     1, L + 1);
-                blk.conv2 = add_conv(p + ".conv2.weight", p + ".bn2", width[L], width[L], 3, 1, 1,
-                                     L + 1);
+                if (variant == 1) {     // Bottleneck: 1x1 -> 3x3 (stride) -> 1x1 (x4)
+                    blk.conv1 = add_conv(p + ".conv1.weight", p + ".bn1", inpl, width[L], 1, 1, 0,
+                                         L + 1);
+                    blk.conv2 = add_conv(p + ".conv2.weight", p + ".bn2", width[L], width[L], 3,
+                                         stride, 1, L + 1);
+                    blk.conv3 = add_conv(p + ".conv3.weight", p + ".bn3", width[L], outpl, 1, 1, 0,
+                                         L + 1);
+                } else {                // BasicBlock: 3x3 (stride) -> 3x3
+                    blk.conv1 = add_conv(p + ".conv1.weight", p + ".bn1", inpl, width[L], 3,
+                                         stride, 1, L + 1);
+                    blk.conv2 = add_conv(p + ".conv2.weight", p + ".bn2", width[L], width[L], 3, 1,
+                                         1, L + 1);
+                    blk.conv3 = -1;
+                }
                 blk.down = -1;
-                if (stride != 1 || inpl != width[L])
+                if (stride != 1 || inpl != outpl)
                     blk.down = add_conv(p + ".downsample.0.weight", p + ".downsample.1", inpl,
-                                        width[L], 1, stride, 0, L + 1);
+                                        outpl, 1, stride, 0, L + 1);
                 blocks.push_back(blk);
-                inpl = width[L];
+                inpl = outpl;
             }
         }
+        feat = inpl;
         layer_begin[4] = arena_floats;
         se0 = add_lin("speed_encoder.0", 1, 128);
         se3 = add_lin("speed_encoder.3", 128, 128);
         for (int k = 0; k < 4; ++k) {
             const std::string p = "control_branches." + std::to_string(k);
-            br[k][0] = add_lin(p + ".0", 640, 256);
+            br[k][0] = add_lin(p + ".0", feat + 128, 256);
             br[k][1] = add_lin(p + ".3", 256, 256);
             br[k][2] = add_lin(p + ".6", 256, 3);
         }
-        sp0 = add_lin("speed_predictor.0", 512, 256);
+        sp0 = add_lin("speed_predictor.0", feat, 256);
         sp3 = add_lin("speed_predictor.3", 256, 256);
         sp5 = add_lin("speed_predictor.5", 256, 1);
         seg_begin[0] = layer_begin[4]; seg_end[0] = arena_floats;
@@ -140,9 +161,10 @@ struct Arch {
     }
 };
 
-const Arch& arch() {
-    static const Arch a;
-    return a;
+constexpr int kNumVariants = 2;
+const Arch& arch(int variant = 0) {
+    static const Arch a0(0), a1(1);
+    return variant == 1 ? a1 : a0;
 }
 
 const char* kGroupName[5] = {"stem", "layer1", "layer2", "layer3", "layer4"};
@@ -224,6 +246,7 @@ static int dy_ring_depth() {
 }
 
 struct cilrs_net {
+    const Arch* A = nullptr;               // architecture variant of this plan
     int B, H, W;
     std::vector<ConvG> cg;                 // geometry + workspace offsets (floats) per conv
     int H0, W0, H1, W1;                    // stem conv out, maxpool out
@@ -250,7 +273,7 @@ struct cilrs_net {
     int bwd_nblk_next = 0;                 // fused BN-backward partials waiting for their BN
     BnEvalTable bn_table;
     FoldF16Table f16_table;                // fp16 inference: folded weights / biases / activations
-    size_t f16_w, f16_bias, f16_act[4], f16_act_floats;
+    size_t f16_w, f16_bias, f16_act[5], f16_act_floats;
     // cached hipGraph of the uint8 inference path (fixed pointers)
     hipGraphExec_t graph_exec = nullptr;
     int graph_half = 0;
@@ -446,9 +469,36 @@ size_t cilrs_param_arena_floats(void) { return arch().arena_floats; }
 size_t cilrs_param_count(void) { return arch().count; }
 size_t cilrs_bn_arena_floats(void) { return arch().bn_floats; }
 
+int cilrs_num_variants(void) { return kNumVariants; }
+static bool variant_ok(int v) { return v >= 0 && v < kNumVariants; }
+int cilrs_variant_num_params(int variant) {
+    return variant_ok(variant) ? (int)arch(variant).params.size() : -1;
+}
+int cilrs_variant_num_bn(int variant) {
+    return variant_ok(variant) ? (int)arch(variant).bns.size() : -1;
+}
+size_t cilrs_variant_param_arena_floats(int variant) {
+    return variant_ok(variant) ? arch(variant).arena_floats : 0;
+}
+size_t cilrs_variant_param_count(int variant) {
+    return variant_ok(variant) ? arch(variant).count : 0;
+}
+size_t cilrs_variant_bn_arena_floats(int variant) {
+    return variant_ok(variant) ? arch(variant).bn_floats : 0;
+}
+int cilrs_variant_feature_width(int variant) {
+    return variant_ok(variant) ? arch(variant).feat : -1;
+}
+
 int cilrs_param_info(int i, char* name, int name_cap, size_t* offset, size_t* numel, int* ndim,
                      int* shape4) {
-    const Arch& A = arch();
+    return cilrs_variant_param_info(0, i, name, name_cap, offset, numel, ndim, shape4);
+}
+
+int cilrs_variant_param_info(int variant, int i, char* name, int name_cap, size_t* offset,
+                             size_t* numel, int* ndim, int* shape4) {
+    CILRS_CHECK(variant_ok(variant), "variant %d out of range", variant);
+    const Arch& A = arch(variant);
     CILRS_CHECK(i >= 0 && i < (int)A.params.size(), "param index %d out of range", i);
     const ParamT& p = A.params[i];
     if (name && name_cap > 0) snprintf(name, name_cap, "%s", p.name.c_str());
@@ -461,7 +511,13 @@ int cilrs_param_info(int i, char* name, int name_cap, size_t* offset, size_t* nu
 
 int cilrs_bn_info(int j, char* prefix, int prefix_cap, int* channels, size_t* rm_offset,
                   size_t* rv_offset) {
-    const Arch& A = arch();
+    return cilrs_variant_bn_info(0, j, prefix, prefix_cap, channels, rm_offset, rv_offset);
+}
+
+int cilrs_variant_bn_info(int variant, int j, char* prefix, int prefix_cap, int* channels,
+                          size_t* rm_offset, size_t* rv_offset) {
+    CILRS_CHECK(variant_ok(variant), "variant %d out of range", variant);
+    const Arch& A = arch(variant);
     CILRS_CHECK(j >= 0 && j < (int)A.bns.size(), "bn index %d out of range", j);
     const BnT& b = A.bns[j];
     if (prefix && prefix_cap > 0) snprintf(prefix, prefix_cap, "%s", b.prefix.c_str());
@@ -482,11 +538,18 @@ int cilrs_segment_range(int seg, size_t* begin, size_t* end) {
 // plan creation
 // ------------------------------------------------------------------------------------------------
 int cilrs_net_create(int batch, int height, int width, cilrs_net** out) {
+    return cilrs_net_create_variant(0, batch, height, width, out);
+}
+
+int cilrs_net_create_variant(int variant, int batch, int height, int width, cilrs_net** out) {
     CILRS_CHECK(out != nullptr, "cilrs_net_create: out is NULL");
+    CILRS_CHECK(variant_ok(variant), "cilrs_net_create: variant %d out of range", variant);
     CILRS_CHECK(batch >= 1 && height >= 32 && width >= 32, "cilrs_net_create: bad geometry %d %d %d",
                 batch, height, width);
-    const Arch& A = arch();
+    const Arch& A = arch(variant);
+    const bool trainable = variant == 0;       // the ResNet-50 variant is inference-only
     cilrs_net* n = new cilrs_net();
+    n->A = &A;
     n->B = batch; n->H = height; n->W = width;
     n->cg.resize(A.convs.size());
     Bump bump;
@@ -501,7 +564,7 @@ int cilrs_net_create(int batch, int height, int width, cilrs_net** out) {
         g.H = height; g.W = width;
         g.Ho = out_dim(height, 7, 2, 3); g.Wo = out_dim(width, 7, 2, 3);
         g.M = B * g.Ho * g.Wo;
-        g.y = bump.take((size_t)g.M * 64);
+        g.y = bump.take(trainable ? (size_t)g.M * 64 : 4);
         g.z = bump.take((size_t)g.M * 64);
         g.stats = bump.take(4 * 64);
         n->H0 = g.Ho; n->W0 = g.Wo;
@@ -509,59 +572,63 @@ int cilrs_net_create(int batch, int height, int width, cilrs_net** out) {
     }
     size_t gmax = (size_t)n->cg[0].M * 64;
     size_t dymax = 0;
+    size_t actmax = (size_t)B * n->H1 * n->W1 * 64;       // largest trunk tensor (elements)
     n->pool = bump.take((size_t)B * n->H1 * n->W1 * 64);
     const size_t argmax_floats = ((size_t)B * n->H1 * n->W1 * 64 + 3) / 4;
     n->argmax_b = bump.take(argmax_floats) * sizeof(float);
     int h = n->H1, w = n->W1;
     size_t slabs_max = 0, ksplit_max = 0;
     auto track = [&](const ConvT& c, const ConvG& g, int x_cin) {
-        WgradArgs wa;
-        memset(&wa, 0, sizeof(wa));
-        wa.N = B; wa.H = g.H; wa.W = g.W; wa.Cin = x_cin; wa.Ho = g.Ho; wa.Wo = g.Wo;
-        wa.Cout = c.cout; wa.KH = wa.KW = c.k; wa.stride = c.stride; wa.pad = c.pad;
-        const size_t sf = wgrad_scratch_floats(wa);
-        if (sf > slabs_max) slabs_max = sf;
+        if (trainable) {
+            WgradArgs wa;
+            memset(&wa, 0, sizeof(wa));
+            wa.N = B; wa.H = g.H; wa.W = g.W; wa.Cin = x_cin; wa.Ho = g.Ho; wa.Wo = g.Wo;
+            wa.Cout = c.cout; wa.KH = wa.KW = c.k; wa.stride = c.stride; wa.pad = c.pad;
+            const size_t sf = wgrad_scratch_floats(wa);
+            if (sf > slabs_max) slabs_max = sf;
+        }
         // split-K scratch: only worthwhile for the small-M layers
         const size_t fwd = (size_t)g.M * c.cout, bwd = (size_t)B * g.H * g.W * c.cin;
         const size_t big = fwd > bwd ? fwd : bwd;
         if (big <= (size_t)6 * 1024 * 1024 && 8 * big > ksplit_max) ksplit_max = 8 * big;
+        if (fwd > actmax) actmax = fwd;
+    };
+    // geometry + activation buffers of one convolution (y: pre-BN output, kept for backward only)
+    auto place = [&](int ci, int in_h, int in_w) {
+        const ConvT& c = A.convs[ci];
+        ConvG& g = n->cg[ci];
+        g.H = in_h; g.W = in_w;
+        g.Ho = out_dim(in_h, c.k, c.stride, c.pad); g.Wo = out_dim(in_w, c.k, c.stride, c.pad);
+        g.M = B * g.Ho * g.Wo;
+        g.y = bump.take(trainable ? (size_t)g.M * c.cout : 4);
+        g.z = bump.take((size_t)g.M * c.cout);
+        g.stats = bump.take(4 * c.cout);
+        track(c, g, c.cin);
     };
     track(A.convs[0], n->cg[0], 4);
     for (const BlockT& blk : A.blocks) {
-        const ConvT& c1 = A.convs[blk.conv1];
-        ConvG& g1 = n->cg[blk.conv1];
-        g1.H = h; g1.W = w;
-        g1.Ho = out_dim(h, 3, c1.stride, 1); g1.Wo = out_dim(w, 3, c1.stride, 1);
-        g1.M = B * g1.Ho * g1.Wo;
-        g1.y = bump.take((size_t)g1.M * c1.cout);
-        g1.z = bump.take((size_t)g1.M * c1.cout);
-        g1.stats = bump.take(4 * c1.cout);
-        track(c1, g1, c1.cin);
-        const ConvT& c2 = A.convs[blk.conv2];
-        ConvG& g2 = n->cg[blk.conv2];
-        g2.H = g1.Ho; g2.W = g1.Wo; g2.Ho = g1.Ho; g2.Wo = g1.Wo; g2.M = g1.M;
-        g2.y = bump.take((size_t)g2.M * c2.cout);
-        g2.z = bump.take((size_t)g2.M * c2.cout);      // block output
-        g2.stats = bump.take(4 * c2.cout);
-        track(c2, g2, c2.cin);
+        place(blk.conv1, h, w);
+        const ConvG& g1 = n->cg[blk.conv1];
+        place(blk.conv2, g1.Ho, g1.Wo);
+        const ConvG& g2 = n->cg[blk.conv2];
+        int oh = g2.Ho, ow = g2.Wo;
+        if (blk.conv3 >= 0) place(blk.conv3, g2.Ho, g2.Wo);
         if (blk.down >= 0) {
-            const ConvT& cd = A.convs[blk.down];
-            ConvG& gd = n->cg[blk.down];
-            gd.H = h; gd.W = w; gd.Ho = g1.Ho; gd.Wo = g1.Wo; gd.M = g1.M;
-            gd.y = bump.take((size_t)gd.M * cd.cout);
-            gd.z = bump.take((size_t)gd.M * cd.cout);
-            gd.stats = bump.take(4 * cd.cout);
-            track(cd, gd, cd.cin);
+            place(blk.down, h, w);
+            CILRS_CHECK(n->cg[blk.down].Ho == oh && n->cg[blk.down].Wo == ow,
+                        "downsample geometry mismatch");
         }
+        const ConvT& c1 = A.convs[blk.conv1];
         const size_t act = (size_t)B * h * w * c1.cin;
         if (act > gmax) gmax = act;
         if ((size_t)g1.M * c1.cout > gmax) gmax = (size_t)g1.M * c1.cout;
         if ((size_t)g1.M * c1.cout > dymax) dymax = (size_t)g1.M * c1.cout;   // trunk dy tensors
-        h = g1.Ho; w = g1.Wo;
+        h = oh; w = ow;
     }
     n->featHW = h * w;
+    const int feat = A.feat, comb = A.feat + 128;
     // heads
-    n->combined = bump.take((size_t)B * 640);
+    n->combined = bump.take((size_t)B * comb);
     n->s1 = bump.take((size_t)B * 128);
     n->p1 = bump.take((size_t)B * 256);
     n->p2 = bump.take((size_t)B * 256);
@@ -570,45 +637,49 @@ int cilrs_net_create(int batch, int height, int width, cilrs_net** out) {
         n->h2[k] = bump.take((size_t)B * 256);
     }
     n->all_out = bump.take((size_t)4 * B * 4);
-    n->dcombined = bump.take((size_t)B * 640);
-    n->ds1 = bump.take((size_t)B * 128);
-    n->dp1 = bump.take((size_t)B * 256);
-    n->dp2 = bump.take((size_t)B * 256);
+    n->dcombined = bump.take(trainable ? (size_t)B * comb : 4);
+    n->ds1 = bump.take(trainable ? (size_t)B * 128 : 4);
+    n->dp1 = bump.take(trainable ? (size_t)B * 256 : 4);
+    n->dp2 = bump.take(trainable ? (size_t)B * 256 : 4);
     for (int k = 0; k < 4; ++k) {
-        n->dh1[k] = bump.take((size_t)B * 256);
-        n->dh2[k] = bump.take((size_t)B * 256);
+        n->dh1[k] = bump.take(trainable ? (size_t)B * 256 : 4);
+        n->dh2[k] = bump.take(trainable ? (size_t)B * 256 : 4);
     }
-    for (int k = 0; k < 5; ++k) n->dcomb_part[k] = bump.take((size_t)B * 640);
+    for (int k = 0; k < 5; ++k) n->dcomb_part[k] = bump.take(trainable ? (size_t)B * comb : 4);
     n->d_all = bump.take((size_t)4 * B * 4);
     n->speed_in = bump.take((size_t)B);
     n->cmd_b = bump.take((size_t)B * 2) * sizeof(float);
     // the heads' wide linears also use the wgrad slabs
-    {
+    if (trainable) {
         WgradArgs wa;
         memset(&wa, 0, sizeof(wa));
-        wa.N = B; wa.H = wa.W = wa.Ho = wa.Wo = 1; wa.Cin = 640; wa.Cout = 256;
+        wa.N = B; wa.H = wa.W = wa.Ho = wa.Wo = 1; wa.Cin = comb; wa.Cout = 256;
         wa.KH = wa.KW = 1; wa.stride = 1;
         const size_t sf = wgrad_scratch_floats(wa);
         if (sf > slabs_max) slabs_max = sf;
     }
+    (void)feat;
+    if (!trainable) { gmax = 4; dymax = 4; }
     n->gmax = gmax;
     for (int i = 0; i < 5; ++i) n->G[i] = bump.take(gmax);
     for (int i = 5; i < kNumG; ++i) n->G[i] = bump.take(dymax);
     {
         size_t need = bn_partial_floats(512);
-        for (size_t ci = 0; ci < A.convs.size(); ++ci) {
-            const size_t t = (size_t)cdiv(n->cg[ci].M, 64) * 2 * A.convs[ci].cout;
-            if (t > need) need = t;
-        }
+        if (trainable)
+            for (size_t ci = 0; ci < A.convs.size(); ++ci) {
+                const size_t t = (size_t)cdiv(n->cg[ci].M, 64) * 2 * A.convs[ci].cout;
+                if (t > need) need = t;
+            }
         n->bn_partial = bump.take(need);
     }
-    n->bn_coef = bump.take(3 * 512);
+    n->bn_coef = bump.take(3 * 2048);
     n->slabs_floats = slabs_max;
-    n->slabs = bump.take(slabs_max);
+    n->slabs = bump.take(slabs_max > 0 ? slabs_max : 4);
     n->ksplit_floats = ksplit_max;
     n->ksplit = bump.take(ksplit_max > 0 ? ksplit_max : 4);
     n->status_b = bump.take(64) * sizeof(float);
     n->tile_cnt = bump.take(kTileCounters);
+    CILRS_CHECK((int)A.convs.size() <= kMaxConvs, "too many convolutions for the BN tables");
     n->bn_table.n = (int)A.convs.size();
     for (size_t ci = 0; ci < A.convs.size(); ++ci) {
         const BnT& b = A.bns[A.convs[ci].bn];
@@ -617,7 +688,7 @@ int cilrs_net_create(int batch, int height, int width, cilrs_net** out) {
         n->bn_table.rm[ci] = (unsigned)b.rm; n->bn_table.rv[ci] = (unsigned)b.rv;
         n->bn_table.stats[ci] = (unsigned)n->cg[ci].stats;
     }
-    {   // fp16 inference arenas (every conv but the stem): folded weights, biases, 4 activations
+    {   // 16-bit inference arenas (every conv but the stem): folded weights, biases, activations
         size_t halfs = 0, floats = 0;
         n->f16_table.n = (int)A.convs.size() - 1;
         for (size_t ci = 1; ci < A.convs.size(); ++ci) {
@@ -634,8 +705,8 @@ int cilrs_net_create(int batch, int height, int width, cilrs_net** out) {
         }
         n->f16_w = bump.take((halfs + 1) / 2);
         n->f16_bias = bump.take(floats);
-        n->f16_act_floats = ((size_t)B * n->H1 * n->W1 * 64 + 1) / 2;     // largest trunk tensor
-        for (int k = 0; k < 4; ++k) n->f16_act[k] = bump.take(n->f16_act_floats);
+        n->f16_act_floats = (actmax + 1) / 2;                              // largest trunk tensor
+        for (int k = 0; k < 5; ++k) n->f16_act[k] = bump.take(n->f16_act_floats);
     }
     n->ws_bytes = bump.off * sizeof(float);
     *out = n;
@@ -668,7 +739,8 @@ int cilrs_dropout(float* a, int rows, int cols, int ld, float p, uint64_t seed, 
 static int forward_from_x4(cilrs_net* net, const cilrs_buffers* bufs, const float* speed,
                            const int64_t* command, int train, float dropout_p, uint64_t seed,
                            float* controls, float* pred_speed, hipStream_t s, int half = 0) {
-    const Arch& A = arch();
+    const Arch& A = *net->A;
+    CILRS_CHECK(!train || A.variant == 0, "the ResNet-50 variant is inference-only");
     float* ws = reinterpret_cast<float*>(bufs->workspace);
     net->ws_base = ws;
     if (zero_counters_once(net, bufs->workspace, s)) return 1;
@@ -762,12 +834,14 @@ static int forward_from_x4(cilrs_net* net, const cilrs_buffers* bufs, const floa
             //      activations, v_mfma_f32_32x32x16_f16 with fp32 accumulation (infer_f16.hip) ----
             cilrs_half* w16 = reinterpret_cast<cilrs_half*>(ws + net->f16_w);
             float* b16 = ws + net->f16_bias;
-            cilrs_half* act[4];
-            for (int k = 0; k < 4; ++k) act[k] = reinterpret_cast<cilrs_half*>(ws + net->f16_act[k]);
+            const int bf16 = half == 2;
+            cilrs_half* act[5];
+            for (int k = 0; k < 5; ++k) act[k] = reinterpret_cast<cilrs_half*>(ws + net->f16_act[k]);
             RUN(net, "transform", 0.0, 0.0, s,
-                launch_fold_bn_f16(net->f16_table, P, ws, w16, b16, s));
+                launch_fold_bn_f16(net->f16_table, P, ws, w16, b16, bf16, s));
             RUN(net, "transform", 0.0, 0.0, s,
-                launch_f32_to_f16(ws + net->pool, act[0], (size_t)B * net->H1 * net->W1 * 64, s));
+                launch_f32_to_f16(ws + net->pool, act[0], (size_t)B * net->H1 * net->W1 * 64, bf16,
+                                  s));
             int ic = 0;                                  // index of the buffer holding `cur`
             auto conv16 = [&](int ci, const cilrs_half* x, const cilrs_half* residual,
                               cilrs_half* y, int relu) -> int {
@@ -777,26 +851,36 @@ static int forward_from_x4(cilrs_net* net, const cilrs_buffers* bufs, const floa
                 memset(&a, 0, sizeof(a));
                 a.x = x; a.w = w16 + net->f16_table.w16[ci - 1];
                 a.bias = b16 + net->f16_table.bias[ci - 1];
-                a.residual = residual; a.y = y;
+                a.residual = residual; a.y = y; a.bf16 = bf16;
                 a.N = B; a.H = g.H; a.W = g.W; a.Cin = c.cin; a.Ho = g.Ho; a.Wo = g.Wo;
                 a.Cout = c.cout; a.K = c.k; a.stride = c.stride; a.pad = c.pad; a.relu = relu;
+                const double bytes = 2.0 * ((double)B * g.H * g.W * c.cin + (double)g.M * c.cout *
+                                            (residual ? 2.0 : 1.0) + (double)c.cout * c.k * c.k * c.cin);
                 RUN(net, std::string("conv_fwd.") + kGroupName[c.group],
-                    2.0 * g.M * c.cout * c.k * c.k * c.cin, 0.0, s, launch_conv_f16(a, s));
+                    2.0 * g.M * c.cout * c.k * c.k * c.cin, bytes, s, launch_conv_f16(a, s));
                 return 0;
             };
             for (const BlockT& blk : A.blocks) {
-                const int it1 = (ic + 1) & 3, iid = (ic + 2) & 3, io = (ic + 3) & 3;
+                // five rotating buffers: block input, two intermediates, projected identity, output
+                const int it1 = (ic + 1) % 5, it2 = (ic + 2) % 5, iid = (ic + 3) % 5,
+                          io = (ic + 4) % 5;
                 if (conv16(blk.conv1, act[ic], nullptr, act[it1], 1)) return 1;
                 const cilrs_half* identity = act[ic];
                 if (blk.down >= 0) {
                     if (conv16(blk.down, act[ic], nullptr, act[iid], 0)) return 1;
                     identity = act[iid];
                 }
-                if (conv16(blk.conv2, act[it1], identity, act[io], 1)) return 1;
+                if (blk.conv3 >= 0) {
+                    if (conv16(blk.conv2, act[it1], nullptr, act[it2], 1)) return 1;
+                    if (conv16(blk.conv3, act[it2], identity, act[io], 1)) return 1;
+                } else {
+                    if (conv16(blk.conv2, act[it1], identity, act[io], 1)) return 1;
+                }
                 ic = io;
             }
             RUN(net, "heads_fwd", 0.0, 0.0, s,
-                launch_avgpool_f16(act[ic], ws + net->combined, B, net->featHW, 512, 640, s));
+                launch_avgpool_f16(act[ic], ws + net->combined, B, net->featHW, A.feat,
+                                   A.feat + 128, bf16, s));
             cur = nullptr;                               // features already pooled into `combined`
         } else {
         // a layer with few output pixels (single-frame inference) takes the one-launch
@@ -832,14 +916,23 @@ static int forward_from_x4(cilrs_net* net, const cilrs_buffers* bufs, const floa
                 if (conv_eval(cd, gd, cur, ws + gd.z, 0, nullptr, 0)) return 1;
                 identity = ws + gd.z;
             }
-            if (conv_eval(c2, g2, ws + g1.z, ws + g2.z, 0, identity, 1)) return 1;
-            cur = ws + g2.z;
+            if (blk.conv3 >= 0) {      // Bottleneck: 1x1 -> 3x3 -> 1x1 (+ identity)
+                const ConvT& c3 = A.convs[blk.conv3];
+                const ConvG& g3 = net->cg[blk.conv3];
+                if (conv_eval(c2, g2, ws + g1.z, ws + g2.z, 1, nullptr, 0)) return 1;
+                if (conv_eval(c3, g3, ws + g2.z, ws + g3.z, 0, identity, 1)) return 1;
+                cur = ws + g3.z;
+            } else {
+                if (conv_eval(c2, g2, ws + g1.z, ws + g2.z, 0, identity, 1)) return 1;
+                cur = ws + g2.z;
+            }
         }
         }
     }
 
     int* status = reinterpret_cast<int*>(reinterpret_cast<char*>(bufs->workspace) + net->status_b);
-    if (!train && B <= kHeadsSmallMaxB) {
+    const int feat = A.feat, comb = A.feat + 128;
+    if (!train && B <= kHeadsSmallMaxB && A.variant == 0) {
         // ---- inference at control-loop batch sizes: 4 launches, commanded branch only ----
         RUN(net, "heads_fwd", 0.0, 0.0, s,
             launch_heads_small_pre(cur, net->featHW, speed, P + A.se0.w, P + A.se0.b, P + A.se3.w,
@@ -881,7 +974,7 @@ static int forward_from_x4(cilrs_net* net, const cilrs_buffers* bufs, const floa
     // ---- avgpool + flatten -> combined[:, 0:512] ----
     if (cur != nullptr)
         RUN(net, "heads_fwd", 0.0, 0.0, s,
-            launch_avgpool_fwd(cur, ws + net->combined, B, net->featHW, 512, 640, s));
+            launch_avgpool_fwd(cur, ws + net->combined, B, net->featHW, feat, comb, s));
 
     if (train) {   // backward needs the inputs of the heads
         CILRS_HIP(hipMemcpyAsync(ws + net->speed_in, speed, (size_t)B * sizeof(float),
@@ -910,12 +1003,12 @@ static int forward_from_x4(cilrs_net* net, const cilrs_buffers* bufs, const floa
     memset(&h, 0, sizeof(h));
     fwd_group(h.g[0], speed, 1, A.se0, ws + net->s1, 128, 0);
     if (run_fwd(h, 1, 1)) return 1;
-    fwd_group(h.g[0], ws + net->s1, 128, A.se3, ws + net->combined + 512, 640, kNoDrop);
+    fwd_group(h.g[0], ws + net->s1, 128, A.se3, ws + net->combined + feat, comb, kNoDrop);
     if (run_fwd(h, 1, 1)) return 1;
     // ---- 4 branches (all evaluated, :394-396) + speed predictor (:383-387, 393), layer by layer
     for (int k = 0; k < 4; ++k)
-        fwd_group(h.g[k], ws + net->combined, 640, A.br[k][0], ws + net->h1[k], 256, 1 + 2 * k);
-    fwd_group(h.g[4], ws + net->combined, 640, A.sp0, ws + net->p1, 256, 9);
+        fwd_group(h.g[k], ws + net->combined, comb, A.br[k][0], ws + net->h1[k], 256, 1 + 2 * k);
+    fwd_group(h.g[4], ws + net->combined, comb, A.sp0, ws + net->p1, 256, 9);
     if (run_fwd(h, 5, 1)) return 1;
     for (int k = 0; k < 4; ++k)
         fwd_group(h.g[k], ws + net->h1[k], 256, A.br[k][1], ws + net->h2[k], 256, 2 + 2 * k);
@@ -1008,13 +1101,30 @@ int cilrs_net_forward_u8_f16(cilrs_net* net, const cilrs_buffers* bufs, const ui
     return forward_from_x4(net, bufs, speed, command, 0, 0.f, 0, controls, pred_speed, s, 1);
 }
 
+int cilrs_net_forward_u8_bf16(cilrs_net* net, const cilrs_buffers* bufs, const uint8_t* frames,
+                              const float* speed, const int64_t* command, float* controls,
+                              float* pred_speed, void* stream) {
+    if (check_bufs(net, bufs, false)) return 1;
+    CILRS_CHECK(frames && speed && command && controls && pred_speed,
+                "forward_u8_bf16: NULL tensor");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    float* ws = reinterpret_cast<float*>(bufs->workspace);
+    CILRS_HIP(hipMemsetAsync(reinterpret_cast<char*>(bufs->workspace) + net->status_b, 0, 16, s));
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    RUN(net, "transform", 0.0, 0.0, s,
+        launch_u8hwc_to_nhwc4(frames, ws + net->x4, (size_t)net->B * net->H * net->W, mean, stdv,
+                              s));
+    return forward_from_x4(net, bufs, speed, command, 0, 0.f, 0, controls, pred_speed, s, 2);
+}
+
 // Same as cilrs_net_forward_u8, replayed from a cached hipGraph (one launch per frame instead of
 // ~80): the B=1 control-loop path (autonomous_drive.py:908-920) is launch-latency bound.  The
 // graph is re-captured when any pointer changes.  `stream` must not be the legacy NULL stream.
 static int forward_u8_graph(cilrs_net* net, const cilrs_buffers* bufs, const uint8_t* frames,
                             const float* speed, const int64_t* command, float* controls,
                             float* pred_speed, void* stream, int half) {
-    auto eager = half ? cilrs_net_forward_u8_f16 : cilrs_net_forward_u8;
+    auto eager = half == 2 ? cilrs_net_forward_u8_bf16
+                 : half ? cilrs_net_forward_u8_f16 : cilrs_net_forward_u8;
     if (check_bufs(net, bufs, false)) return 1;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     CILRS_CHECK(s != nullptr, "forward_u8_graph: capture needs a non-default stream");
@@ -1063,6 +1173,13 @@ int cilrs_net_forward_u8_f16_graph(cilrs_net* net, const cilrs_buffers* bufs,
     return forward_u8_graph(net, bufs, frames, speed, command, controls, pred_speed, stream, 1);
 }
 
+int cilrs_net_forward_u8_bf16_graph(cilrs_net* net, const cilrs_buffers* bufs,
+                                    const uint8_t* frames, const float* speed,
+                                    const int64_t* command, float* controls, float* pred_speed,
+                                    void* stream) {
+    return forward_u8_graph(net, bufs, frames, speed, command, controls, pred_speed, stream, 2);
+}
+
 // ------------------------------------------------------------------------------------------------
 // backward
 // ------------------------------------------------------------------------------------------------
@@ -1072,6 +1189,7 @@ static int backward_heads(cilrs_net* net, const cilrs_buffers* bufs, const float
 int cilrs_net_backward(cilrs_net* net, const cilrs_buffers* bufs, const float* dcontrols,
                        const float* dpred_speed, int seg_begin, int seg_end, void* stream) {
     if (check_bufs(net, bufs, true)) return 1;
+    CILRS_CHECK(net->A->variant == 0, "the ResNet-50 variant is inference-only");
     CILRS_CHECK(net->trained_fwd, "backward needs a preceding train-mode forward on this plan");
     CILRS_CHECK(0 <= seg_begin && seg_begin <= seg_end && seg_end <= 6, "bad segment range");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);

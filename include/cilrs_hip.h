@@ -49,6 +49,27 @@ int cilrs_bn_info(int j, char* prefix, int prefix_cap, int* channels, size_t* rm
                   size_t* rv_offset);
 size_t cilrs_bn_arena_floats(void);
 
+/* ---- architecture variants ----------------------------------------------------------------------
+ * variant 0: the reference's network (ResNet-34 trunk, autonomous_drive.py:365-370) -- everything
+ *            above describes it.
+ * variant 1: BASELINE.json configs[3] "ResNet-50 backbone variant": torchvision-style Bottleneck
+ *            stacks [3,4,6,3] (stride on the 3x3 convolution), 2048-d features into the same
+ *            speed encoder / four branches / speed predictor (first Linear layers 2176 and 2048
+ *            wide).  The reference has no such model: parity is against the build's own CPU
+ *            restatement.  Inference only (fp32, fp16 or bf16 trunk); train-mode forward and
+ *            backward return an error. */
+int cilrs_num_variants(void);
+int cilrs_variant_num_params(int variant);
+int cilrs_variant_num_bn(int variant);
+size_t cilrs_variant_param_arena_floats(int variant);
+size_t cilrs_variant_param_count(int variant);
+size_t cilrs_variant_bn_arena_floats(int variant);
+int cilrs_variant_feature_width(int variant);
+int cilrs_variant_param_info(int variant, int i, char* name, int name_cap, size_t* offset,
+                             size_t* numel, int* ndim, int* shape4);
+int cilrs_variant_bn_info(int variant, int j, char* prefix, int prefix_cap, int* channels,
+                          size_t* rm_offset, size_t* rv_offset);
+
 /* ---- network plan ----------------------------------------------------------------------------- */
 typedef struct {
     float* params;          /* parameter arena                               */
@@ -60,6 +81,7 @@ typedef struct {
 
 /* plan for a fixed batch / frame size (reference: B x 3 x 88 x 200) */
 int cilrs_net_create(int batch, int height, int width, cilrs_net** out);
+int cilrs_net_create_variant(int variant, int batch, int height, int width, cilrs_net** out);
 void cilrs_net_destroy(cilrs_net* net);
 size_t cilrs_net_workspace_bytes(const cilrs_net* net);
 
@@ -119,6 +141,17 @@ int cilrs_net_forward_u8_f16_graph(cilrs_net* net, const cilrs_buffers* bufs,
                                    const uint8_t* frames, const float* speed,
                                    const int64_t* command, float* controls, float* pred_speed,
                                    void* stream);
+
+/* The same with the trunk in bf16 (v_mfma_f32_32x32x16_bf16, fp32 accumulation): the "bf16 MFMA
+ * path" of BASELINE.json configs[3]; works for both variants.  bf16 keeps 8 significant bits:
+ * outputs agree with the fp32 path to ~1e-2. */
+int cilrs_net_forward_u8_bf16(cilrs_net* net, const cilrs_buffers* bufs, const uint8_t* frames,
+                              const float* speed, const int64_t* command, float* controls,
+                              float* pred_speed, void* stream);
+int cilrs_net_forward_u8_bf16_graph(cilrs_net* net, const cilrs_buffers* bufs,
+                                    const uint8_t* frames, const float* speed,
+                                    const int64_t* command, float* controls, float* pred_speed,
+                                    void* stream);
 
 /* cilrs_net_forward_u8 replayed from a cached hipGraph (re-captured when a pointer changes);
  * `stream` must be a non-default stream.  Single-frame control loop: predict_controls,

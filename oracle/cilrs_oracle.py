@@ -395,8 +395,8 @@ def portable_state_dict(template_sd, seed: int = 0):
             fan_in = int(np.prod(shape[1:]))
             a = math.sqrt(3.0 / fan_in)                       # var(w) = 1/fan_in
             v = (2.0 * u - 1.0) * a
-        elif name.endswith("bn2.weight"):                     # residual-branch BN gamma: small,
-            v = 0.2 + 0.3 * u                                 # keeps eval-mode activations O(1)
+        elif name.endswith("bn2.weight") or name.endswith("bn3.weight"):
+            v = 0.2 + 0.3 * u       # residual-branch BN gamma: small, keeps eval activations O(1)
         elif name.endswith(".weight"):                        # other BN gammas
             v = 0.7 + 0.6 * u
         else:                                                 # BN beta, linear bias

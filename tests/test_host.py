@@ -500,3 +500,31 @@ def test_checkpoint_written_the_reference_way_loads(tmp_path):
     torch.save({"model_state_dict": src.state_dict(), "x": fractions.Fraction(1, 3)}, evil)
     with pytest.raises(Exception):
         checkpoint.load_file(evil)
+
+
+def test_resnet50_variant_layout_matches_its_oracle():
+    """BASELINE.json configs[3] (ResNet-50 variant; the reference has no such model): the module,
+    the engine's arena layout (C-ABI variant 1) and the CPU definition agree on every parameter
+    name / shape / order; the trunk has torchvision ResNet-50's parameter count without its fc."""
+    import resnet50_oracle as R
+    from cilrs_mi355 import CILRSResNet50
+    from cilrs_mi355 import _lib as L
+    from cilrs_mi355.engine import _layout
+    orc = R.CILRSResNet50Oracle()
+    assert sum(p.numel() for p in orc.visual_encoder.parameters()) == R.TRUNK_PARAMS == 23_508_032
+    m = CILRSResNet50(4, 0.0)
+    assert list(m.state_dict().keys()) == list(orc.state_dict().keys())
+    for (k, a), (_, b) in zip(m.state_dict().items(), orc.state_dict().items()):
+        assert a.shape == b.shape and a.dtype == b.dtype, k
+    lay, bns = _layout(1)
+    assert [(n, s) for n, _, _, s in lay] == [(n, tuple(p.shape)) for n, p in m.named_parameters()]
+    lib = L.lib()
+    assert lib.cilrs_num_variants() == 2
+    assert lib.cilrs_variant_param_count(1) == sum(p.numel() for p in orc.parameters())
+    assert lib.cilrs_variant_feature_width(1) == 2048 and lib.cilrs_variant_feature_width(0) == 512
+    assert lib.cilrs_variant_num_bn(1) == len(bns) == 53
+    # variant 0 through the variant API == the plain API (the reference's network)
+    assert lib.cilrs_variant_param_count(0) == lib.cilrs_param_count() == 22_421_453
+    assert _layout(0)[0][:3] == _layout()[0][:3]
+    with pytest.raises(RuntimeError):
+        m.train()(torch.zeros(1, 3, 176, 400), torch.zeros(1), torch.zeros(1, dtype=torch.long))

@@ -628,7 +628,11 @@ def _grad_budget_check(tag, named_oracle_params, gv, g64, coef):
         e_cpu = float((p.grad.double() - ref64).norm()) / nrm
         assert e_gpu <= max(4.0 * e_cpu, 5e-3), (tag, n, e_gpu, e_cpu)
         gmax = max(float(ref64.abs().max()), 1e-12)
-        assert float((mine - ref64).abs().max()) <= 5e-2 * gmax, (tag, n)
+        m_gpu = float((mine - ref64).abs().max())
+        m_cpu = float((p.grad.double() - ref64).abs().max())
+        # a flipped ReLU / max-pool decision moves single elements by a few % of max|g| -- in the
+        # fp32 CPU path as much as here; budget against its own worst element
+        assert m_gpu <= max(4.0 * m_cpu, 5e-2 * gmax), (tag, n, m_gpu, m_cpu, gmax)
         worst_gpu, worst_cpu = max(worst_gpu, e_gpu), max(worst_cpu, e_cpu)
         errs.append((e_gpu, e_cpu))
         dot += float((mine * ref64).sum())
@@ -918,3 +922,74 @@ def test_fit_resume_keeps_best_checkpoint_patience_and_history(tmp_path):
     rows = open(tmp_path / "training_history.csv").read().strip().split("\n")
     assert [r.split(",")[0] for r in rows[1:3]] == ["1", "2"] and len(rows) >= 4
     assert any("early stopping" in str(l) for l in logs) or len(rows) == 5
+
+
+# ---- BASELINE.json configs[3]: ResNet-50 variant, 176x400 input, bf16 matrix path ---------------
+def make_model50(seed=0):
+    from cilrs_mi355 import CILRSResNet50
+    m = CILRSResNet50(4, 0.0)
+    m.load_state_dict(O.portable_state_dict(m.state_dict(), seed), strict=True)
+    return m.cuda().eval()
+
+
+# bf16 keeps 8 significant bits (fp16: 11): one rounding per stored activation through 53 folded
+# convolutions.  Outputs are O(0.1 .. 1); the tolerance SURVEY.md 8d states for fp16 is 1e-2.
+TOL_BF16 = 3e-2
+TOL_F16 = 1e-2
+
+
+def test_resnet50_variant_fp32_and_bf16_forward_vs_its_oracle():
+    """Parity of the variant is against the build's own CPU definition (oracle/resnet50_oracle.py;
+    the reference has no ResNet-50): fp32 eval forward within 1e-4 like the main network, the
+    bf16 and fp16 trunks within their stated tolerances, at BASELINE's 176x400 input."""
+    import resnet50_oracle as R
+    B = 3
+    m = make_model50()
+    orc = R.build_oracle50(0).eval()
+    img, spd, cmd, _, u8 = O.synthetic_batch(B, seed=9, h=176, w=400)
+    with torch.no_grad():
+        oc, os_ = orc(img, spd, cmd)
+        c, s = m(*to_dev(img, spd, cmd))
+    assert (c.cpu() - oc).abs().max() <= TOL_OUT, float((c.cpu() - oc).abs().max())
+    assert (s.cpu() - os_).abs().max() <= TOL_OUT
+    eng = m.engine()
+    frames = torch.from_numpy(u8).cuda()
+    c32, s32 = eng.run_forward_u8(frames, spd.cuda(), cmd.cuda())
+    cb, sb = eng.run_forward_u8(frames, spd.cuda(), cmd.cuda(), half="bf16")
+    ch, sh = eng.run_forward_u8(frames, spd.cuda(), cmd.cuda(), half=True)
+    torch.cuda.synchronize()
+    assert (c32.cpu() - oc).abs().max() <= TOL_OUT
+    eb = max(float((cb.cpu() - oc).abs().max()), float((sb.cpu() - os_).abs().max()))
+    eh = max(float((ch.cpu() - oc).abs().max()), float((sh.cpu() - os_).abs().max()))
+    print(f"ResNet-50 variant: bf16 max abs err {eb:.3e}, fp16 {eh:.3e}")
+    assert eb <= TOL_BF16 and eh <= TOL_F16
+    assert (cb - c32).abs().max() > 0 and (cb - ch).abs().max() > 0     # three arithmetic paths
+    cb2, _ = eng.run_forward_u8(frames, spd.cuda(), cmd.cuda(), half="bf16")
+    assert torch.equal(cb, cb2)                                          # deterministic
+    # other geometry / batch (odd pooling edges), every command present
+    img, spd, cmd, _, u8 = O.synthetic_batch(5, seed=10, h=88, w=200)
+    with torch.no_grad():
+        oc, os_ = orc(img, spd, cmd)
+    cb, sb = eng.run_forward_u8(torch.from_numpy(u8).cuda(), spd.cuda(), cmd.cuda(), half="bf16")
+    assert (cb.cpu() - oc).abs().max() <= TOL_BF16 and (sb.cpu() - os_).abs().max() <= TOL_BF16
+    # hipGraph replay == eager
+    from cilrs_mi355.predict import Predictor
+    pr = Predictor(m, batch=5, use_graph=True, half="bf16")
+    kmh = (spd.numpy().astype(np.float64) * 90.0).tolist()
+    for _ in range(2):
+        got = pr.predict_batch(u8, kmh, cmd.numpy())
+    assert np.abs(got[:, :3] - cb.cpu().numpy()).max() <= 1e-6
+    with pytest.raises(RuntimeError):
+        m.train()(img.cuda(), spd.cuda(), cmd.cuda())                    # inference-only variant
+
+
+def test_bf16_trunk_on_the_reference_network():
+    """The bf16 path also serves the reference's ResNet-34 network (same kernels)."""
+    m = make_model().eval()
+    orc = O.build_oracle(0).eval()
+    img, spd, cmd, _, u8 = O.synthetic_batch(6, seed=123)
+    with torch.no_grad():
+        oc, os_ = orc(img, spd, cmd)
+    eng = m.engine()
+    cb, sb = eng.run_forward_u8(torch.from_numpy(u8).cuda(), spd.cuda(), cmd.cuda(), half="bf16")
+    assert (cb.cpu() - oc).abs().max() <= TOL_BF16 and (sb.cpu() - os_).abs().max() <= TOL_BF16

@@ -398,14 +398,26 @@ def test_conv_auto_plan_at_benchmark_batch(shape):
     assert torch.isfinite(got_dx).all()
     assert (got_dx - want_dx).abs().max() <= _tol(want_dx)
     assert (dxa.cpu() - (want_dx + add)).abs().max() <= _tol(want_dx + add)
-    # K = N*Ho*Wo products per element (up to 140,800): summation-order noise grows like sqrt(K)
+    # K = N*Ho*Wo products per element (up to 140,800): both fp32 results carry summation-order
+    # noise ~ sqrt(K) ulp, so the weight gradient is budgeted against a float64 reference
     want_dw = w.grad.permute(0, 2, 3, 1)
     got_dw = dwd.cpu()
     assert torch.isfinite(got_dw).all()
     err = (got_dw - want_dw).abs().max()
     assert err <= _tol(want_dw, 5e-5), float(err / want_dw.abs().max())
-    rel = float((got_dw.double() - want_dw.double()).norm() / want_dw.double().norm())
-    assert rel <= 2e-6, rel
+    _wgrad_vs_f64(x.detach(), dy, (Cout, Cin, k, k), s, p, got_dw, want_dw)
+
+
+def _wgrad_vs_f64(x, dy, wshape, stride, pad, got_ohwi, cpu32_ohwi):
+    """relative-L2 error of the HIP weight gradient against a float64 computation; it may not
+    exceed twice the error torch's own fp32 CPU path makes (floor 1e-6)."""
+    w64 = torch.zeros(wshape, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), w64, None, stride, pad).backward(dy.double())
+    ref = w64.grad.permute(0, 2, 3, 1)
+    nrm = float(ref.norm())
+    e_hip = float((got_ohwi.double() - ref).norm()) / nrm
+    e_cpu = float((cpu32_ohwi.double() - ref).norm()) / nrm
+    assert e_hip <= max(2.0 * e_cpu, 1e-6), (e_hip, e_cpu)
 
 
 def test_stem_auto_plan_at_benchmark_batch():
@@ -440,7 +452,7 @@ def test_stem_auto_plan_at_benchmark_batch():
     got = dwd.cpu()
     assert torch.isfinite(got).all()
     assert (got - want_dw).abs().max() <= _tol(want_dw, 5e-5)
-    assert float((got.double() - want_dw.double()).norm() / want_dw.double().norm()) <= 2e-6
+    _wgrad_vs_f64(x, dy, (64, 3, 7, 7), 2, 3, got, want_dw)
 
 
 @pytest.mark.parametrize("clip,gscale", [(False, 1.0), (True, 0.5)])
@@ -483,7 +495,7 @@ def test_adam_step_matches_torch_adam(clip, gscale):
             L.check(lib.cilrs_adam_step(L.ptr(pd), L.ptr(gd), L.ptr(m), L.ptr(v), n, lr, b1, b2,
                                         eps, wd, step, clip_ptr, 1.0, stream()))
             torch.cuda.synchronize()
-            assert abs(float(clip_out[0]) - float(tn)) <= 1e-5 * float(tn)
+            assert abs(float(clip_out[0]) - float(tn)) <= 1e-4 * float(tn)    # fp32 vs double sums
             assert abs(float(clip_out[1]) - min(1.0, max_norm / (float(tn) + 1e-6))) <= 1e-6
         else:
             p_ref.grad = g_eff.clone()
