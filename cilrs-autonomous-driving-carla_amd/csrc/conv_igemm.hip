@@ -13,12 +13,22 @@
 // Block = 256 threads = 4 waves; block tile BM x BN, K-tile 32.  Global loads run TWO K-tiles
 // ahead of the MFMAs (two register sets, LDS double-buffered): the measured load-to-use latency
 // under load (~4-6k cycles) is several K-tiles of MFMA work, one tile of prefetch left the matrix
-// pipe ~45 % idle (profiles/r01_prof_a).  Per-tile address work is a 64-bit add and a bit test:
-// row bases and per-row valid-tap masks are computed once, out-of-image taps read a zero page
-// (no divergent branches).  LDS rows are K-contiguous with a 4-float pad (pitch 36 floats): a
-// ds_read_b128 gives one lane four k-values and r -> 9r mod 16 being a bijection makes every
-// 16-lane read group conflict-free.  Lane half h owns k = 8q+4h+e (e = 0..3) of each 8-k group for
-// BOTH operands, so the fmaf chain order is fixed: results are run-to-run deterministic.
+// pipe ~45 % idle.  Operands come through buffer loads: a wave-uniform base plus a 32-bit byte
+// offset per row; per-row valid-tap masks are computed once, and a tap that falls outside the image
+// is given the offset ~0, which is out of the buffer's range, so the hardware returns zeros -- no
+// zero page, no pointer select, no divergent branch in the K loop (the generic-tap path of the
+// 3-channel stem still gathers through pointers and a zero page).  LDS rows are K-contiguous; the
+// 64x64 tile uses an unpadded XOR-swizzled image (32 KB per block, five blocks per CU), the larger
+// tiles a 4-float pad (pitch 36 floats): a ds_read_b128 gives one lane four k-values and every
+// 16-lane read group is conflict-free.  Lane half h owns k = 8q+4h+e (e = 0..3) of each 8-k group
+// for BOTH operands, so the fmaf chain order is fixed: results are run-to-run deterministic.
+//
+// What a launch of this kernel costs at the benchmark sizes (tools/fill_probe.py, MI355X): with
+// the grid an exact multiple of the 1,280 resident blocks the 64x64 tile sustains 126-134 TFLOP/s
+// (0.80-0.85 of the fp32 matrix peak) from the second round on; every launch adds a fixed ~12 us
+// (T = 11.9 us + 2.5 us per K-tile for one round of five blocks per CU: dependent-launch boundary,
+// write-back of the ~20 MB of dirty output, cold first tiles, index set-up), and a layer whose tile
+// count is not a multiple of the slots idles the short CUs (layer2: 1,100 tiles on 1,280 slots).
 #include "common.h"
 
 #include <stdlib.h>

@@ -26,7 +26,9 @@ constexpr int BKP = 32;   // pixels per K-tile
 template <int BT, bool TAP_UNIFORM, bool PIN>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a, const int Mpix,
                                                             const int splits, const int tiles_ci,
-                                                            const int Ncols) {
+                                                            const int Ncols, const int ntiles_x,
+                                                            const int ntiles_co,
+                                                            const int xcd_group) {
     // block tile BT(co) x BT(ci-columns); 4 waves as 2x2, wave tile (BT/2)^2
     constexpr int WT = BT / 2, T = WT / 32;
     constexpr int QPR = BT / 4;            // float4 quads per tile row
@@ -42,9 +44,25 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a, c
     const int l31 = lane & 31, lh = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
 
-    const int ntile = blockIdx.x;          // column tile: (tap, ci-tile) or flattened columns
-    const int co0 = blockIdx.y * BT;
-    const int z = blockIdx.z;
+    // 1-D grid over (column tile, co tile, K-slab), column tile fastest.  The hardware deals
+    // consecutive block ids round-robin over the 8 XCDs (each with its own L2), so in plain order
+    // the column tiles of ONE K-slab -- which all read the same dy rows and, tap-shifted, the
+    // same x rows -- land on all eight L2s and every slab crosses the fabric up to eight times.
+    // xcd_group != 0 hands each XCD a contiguous run of logical ids instead, so a slab's tiles
+    // share one L2.  Measured on MI355X (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per launch, B=128):
+    // 263 MB -> 69 MB, but the kernels run 7-15 % SLOWER (the re-reads were Infinity-Cache hits at
+    // ~2.3 TB/s, far from a bound, and nine blocks marching through the same lines of one L2 in
+    // lock-step cost more than they save), so plain order stays the default (CILRS_WGRAD_XCD=1).
+    int logical = (int)blockIdx.x;
+    if (xcd_group) {
+        const int nwg = (int)gridDim.x, bid = (int)blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        logical = base + (bid >> 3);
+    }
+    const int ntile = logical % ntiles_x;  // column tile: (tap, ci-tile) or flattened columns
+    const int co0 = ((logical / ntiles_x) % ntiles_co) * BT;
+    const int z = logical / (ntiles_x * ntiles_co);
 
     // K (pixel) range of this split, in whole K-tiles
     const int KT = (Mpix + BKP - 1) / BKP;
@@ -382,7 +400,9 @@ int launch_conv_wgrad(const WgradArgs& a, hipStream_t s) {
                 "conv_wgrad: pointers must be 16-byte aligned");
     const WPlan p = plan(a);
     const int Mpix = a.N * a.Ho * a.Wo;
-    dim3 grid(p.ntiles, a.Cout / p.bt, p.splits);
+    const int ntiles_co = a.Cout / p.bt;
+    static const int xcd = getenv("CILRS_WGRAD_XCD") ? atoi(getenv("CILRS_WGRAD_XCD")) : 0;
+    dim3 grid(p.ntiles * ntiles_co * p.splits, 1, 1);
     const size_t lds = (size_t)4 * BKP * (p.bt + 4) * sizeof(float);
     // CILRS_WGRAD_PIN=0: let the compiler place the LDS reads (A/B switch for tools/conv_bench.py)
     static const bool pin = getenv("CILRS_WGRAD_PIN") ? atoi(getenv("CILRS_WGRAD_PIN")) != 0 : true;
@@ -399,20 +419,20 @@ int launch_conv_wgrad(const WgradArgs& a, hipStream_t s) {
         }
         if (pin)
             conv_wgrad_kernel<128, true, true><<<grid, 256, lds, s>>>(a, Mpix, p.splits,
-                                                                      p.tiles_ci, p.ncols);
+                                                                      p.tiles_ci, p.ncols, p.ntiles, ntiles_co, xcd);
         else
             conv_wgrad_kernel<128, true, false><<<grid, 256, lds, s>>>(a, Mpix, p.splits,
-                                                                       p.tiles_ci, p.ncols);
+                                                                       p.tiles_ci, p.ncols, p.ntiles, ntiles_co, xcd);
     } else if (p.uniform) {
         if (pin)
             conv_wgrad_kernel<64, true, true><<<grid, 256, lds, s>>>(a, Mpix, p.splits,
-                                                                     p.tiles_ci, p.ncols);
+                                                                     p.tiles_ci, p.ncols, p.ntiles, ntiles_co, xcd);
         else
             conv_wgrad_kernel<64, true, false><<<grid, 256, lds, s>>>(a, Mpix, p.splits,
-                                                                      p.tiles_ci, p.ncols);
+                                                                      p.tiles_ci, p.ncols, p.ntiles, ntiles_co, xcd);
     } else {
         conv_wgrad_kernel<64, false, false><<<grid, 256, lds, s>>>(a, Mpix, p.splits, p.tiles_ci,
-                                                                   p.ncols);
+                                                                   p.ncols, p.ntiles, ntiles_co, xcd);
     }
     CILRS_LAUNCH_CHECK();
     const size_t n_src = (size_t)a.Cout * p.ncols;
