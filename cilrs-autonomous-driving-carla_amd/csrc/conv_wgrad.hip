@@ -48,11 +48,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a, c
     // consecutive block ids round-robin over the 8 XCDs (each with its own L2), so in plain order
     // the column tiles of ONE K-slab -- which all read the same dy rows and, tap-shifted, the
     // same x rows -- land on all eight L2s and every slab crosses the fabric up to eight times.
-    // xcd_group != 0 hands each XCD a contiguous run of logical ids instead, so a slab's tiles
-    // share one L2.  Measured on MI355X (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per launch, B=128):
-    // 263 MB -> 69 MB, but the kernels run 7-15 % SLOWER (the re-reads were Infinity-Cache hits at
-    // ~2.3 TB/s, far from a bound, and nine blocks marching through the same lines of one L2 in
-    // lock-step cost more than they save), so plain order stays the default (CILRS_WGRAD_XCD=1).
+    // xcd_group != 0 (default) hands each XCD a contiguous run of logical ids instead, so a slab's
+    // tiles share one L2.  Measured on MI355X at B=128 (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE per
+    // launch): 263 MB -> 69 MB.  Alone on the chip the kernels then run 7-15 % slower (the
+    // re-reads were Infinity-Cache hits at ~2.3 TB/s, far from a bound, and nine blocks marching
+    // through the same lines of one L2 in lock-step cost more than they save); in the training
+    // step, where they share the chip with the data-gradient chain, the step is 0.7 % FASTER
+    // (11.79 vs 11.88 ms, interleaved A/B on one box): the fabric traffic they no longer generate
+    // is the other stream's.  CILRS_WGRAD_XCD=0 restores plain order.
     int logical = (int)blockIdx.x;
     if (xcd_group) {
         const int nwg = (int)gridDim.x, bid = (int)blockIdx.x;
@@ -401,7 +404,7 @@ int launch_conv_wgrad(const WgradArgs& a, hipStream_t s) {
     const WPlan p = plan(a);
     const int Mpix = a.N * a.Ho * a.Wo;
     const int ntiles_co = a.Cout / p.bt;
-    static const int xcd = getenv("CILRS_WGRAD_XCD") ? atoi(getenv("CILRS_WGRAD_XCD")) : 0;
+    static const int xcd = getenv("CILRS_WGRAD_XCD") ? atoi(getenv("CILRS_WGRAD_XCD")) : 1;
     dim3 grid(p.ntiles * ntiles_co * p.splits, 1, 1);
     const size_t lds = (size_t)4 * BKP * (p.bt + 4) * sizeof(float);
     // CILRS_WGRAD_PIN=0: let the compiler place the LDS reads (A/B switch for tools/conv_bench.py)
