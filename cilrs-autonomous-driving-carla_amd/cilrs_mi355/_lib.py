@@ -56,6 +56,7 @@ SIGNATURES = {
     "cilrs_net_destroy": (None, [vp]),
     "cilrs_net_workspace_bytes": (sz, [vp]),
     "cilrs_net_status_offset": (sz, [vp]),
+    "cilrs_net_set_weights_key": (i32, [vp, u64]),
     "cilrs_dropout": (i32, [vp, i32, i32, i32, f32, u64, i32, vp]),
     "cilrs_net_forward": (i32, [vp, C.POINTER(Buffers), vp, C.c_long, C.c_long, C.c_long,
                                 C.c_long, vp, vp, i32, f32, u64, vp, vp, vp]),

@@ -179,6 +179,7 @@ class Engine:
         self.bufs = {}
         self.last_plan = None
         self._scratch_grads = None        # second gradient arena (autograd accumulation only)
+        self.weights_epoch = 1            # bumped by every kernel-side write to params / BN buffers
 
     # ------------------------------------------------------------------------------------------
     def is_attached(self) -> bool:
@@ -199,6 +200,17 @@ class Engine:
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def weights_key(self) -> int:
+        """Non-zero value that changes whenever the parameters or BatchNorm buffers may have
+        changed.  O(1) -- it sits on the single-frame latency path.  `weights_epoch` is bumped by
+        every kernel-side write (train-mode forward, fused Adam), by load_state_dict and by every
+        train()/eval() switch of the module (model.py hooks); code that writes parameters in
+        place by other means while the module stays in eval mode calls CILRS.weights_changed()."""
+        return (self.weights_epoch * 0xD6E8FEB86659FD93) & 0xFFFFFFFFFFFFFFFF or 1
+
+    def _announce_weights(self, pl):
+        L.check(L.lib().cilrs_net_set_weights_key(pl.handle, self.weights_key()))
 
     # ------------------------------------------------------------------------------------------
     def _check_inputs(self, image, speed, command):
@@ -225,6 +237,9 @@ class Engine:
         controls = torch.empty(b, 3, dtype=torch.float32, device=self.device)
         pred_speed = torch.empty(b, dtype=torch.float32, device=self.device)
         sn, sc, sh, sw = image.stride()
+        if train:
+            self.weights_epoch += 1           # BN running statistics are about to move
+        self._announce_weights(pl)
         L.check(L.lib().cilrs_net_forward(
             pl.handle, C.byref(self.bufs[(pl.batch, pl.h, pl.w)]), L.ptr(image), sn, sc, sh, sw,
             L.ptr(speed), L.ptr(command), 1 if train else 0, float(dropout_p), int(seed),
@@ -262,6 +277,7 @@ class Engine:
             fn = lib.cilrs_net_forward_u8_f16_graph if graph else lib.cilrs_net_forward_u8_f16
         else:
             fn = lib.cilrs_net_forward_u8_graph if graph else lib.cilrs_net_forward_u8
+        self._announce_weights(pl)
         L.check(fn(pl.handle, C.byref(self.bufs[(pl.batch, pl.h, pl.w)]), L.ptr(frames_u8),
                    L.ptr(speed.contiguous()), L.ptr(command.contiguous()), L.ptr(controls),
                    L.ptr(pred_speed), self._stream()))
@@ -282,6 +298,7 @@ class Engine:
         else:
             controls, pred_speed = out
         hs, ws, px = frames_u8.size(1), frames_u8.size(2), frames_u8.size(3)
+        self._announce_weights(pl)
         L.check(L.lib().cilrs_net_forward_camera(
             pl.handle, C.byref(self.bufs[(pl.batch, pl.h, pl.w)]), L.ptr(frames_u8), hs, ws, px,
             ws * px, hs * ws * px, L.ptr(speed.contiguous()), L.ptr(command.contiguous()),

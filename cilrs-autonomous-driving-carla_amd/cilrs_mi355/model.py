@@ -121,6 +121,22 @@ class CILRS(nn.Module):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
         self._engine = None
         self._dropout_calls = 0
+        # anything that may rewrite parameters / buffers invalidates what the engine derived
+        # from them for inference (engine.weights_key)
+        self.register_load_state_dict_post_hook(lambda module, _keys: module.weights_changed())
+
+    def weights_changed(self):
+        """Tell the engine that parameters or BatchNorm buffers were modified in place (it then
+        re-derives its cached inference state: folded BatchNorm scale/shift, 16-bit weights).
+        Called automatically by load_state_dict, by train()/eval() switches and by the engine's
+        own training kernels; needed only after other in-place edits made in eval mode."""
+        if self._engine is not None:
+            self._engine.weights_epoch += 1
+
+    def train(self, mode=True):
+        if mode != self.training:
+            self.weights_changed()
+        return super().train(mode)
 
     # -- engine plumbing ---------------------------------------------------------------------
     def _apply(self, fn, *a, **k):

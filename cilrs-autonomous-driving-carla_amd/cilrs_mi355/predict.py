@@ -36,29 +36,49 @@ class Predictor:
         self.use_graph = use_graph
         self.half = half              # fp16 BasicBlock trunk (batched serving, BASELINE config 5)
         self.stream = torch.cuda.Stream(device=dev)      # hipGraph capture needs its own stream
-        self.ctrl_dev = torch.empty(batch, 3, dtype=torch.float32, device=dev)
-        self.spd_out_dev = torch.empty(batch, dtype=torch.float32, device=dev)
-        self.ctrl_host = torch.empty(batch, 3, dtype=torch.float32).pin_memory()
-        self.spd_out_host = torch.empty(batch, dtype=torch.float32).pin_memory()
-        self._ctrl_np = self.ctrl_host.numpy()
-        self._spd_np = self.spd_out_host.numpy()
-        self.status_host = torch.zeros(4, dtype=torch.int32).pin_memory()
-        self._status_np = self.status_host.numpy()
-        self.frames_host = torch.empty(batch, height, width, 3, dtype=torch.uint8).pin_memory()
-        self.frames_dev = torch.empty(batch, height, width, 3, dtype=torch.uint8, device=dev)
-        self.speed_host = torch.empty(batch, dtype=torch.float32).pin_memory()
-        self.cmd_host = torch.empty(batch, dtype=torch.int64).pin_memory()
-        self.speed_dev = torch.empty(batch, dtype=torch.float32, device=dev)
-        self.cmd_dev = torch.empty(batch, dtype=torch.int64, device=dev)
+        # ONE pinned host buffer and ONE device buffer per direction: a tick costs one H2D copy
+        # (frames | speed | command, packed) and one D2H copy (controls | predicted speed)
+        nfr = batch * height * width * 3
+        o_spd = (nfr + 15) // 16 * 16
+        o_cmd = (o_spd + 4 * batch + 7) // 8 * 8
+        self.in_host = torch.zeros(o_cmd + 8 * batch, dtype=torch.uint8).pin_memory()
+        self.in_dev = torch.zeros_like(self.in_host, device=dev)
+
+        def views(buf):
+            return (buf[:nfr].view(batch, height, width, 3),
+                    buf[o_spd:o_spd + 4 * batch].view(torch.float32),
+                    buf[o_cmd:o_cmd + 8 * batch].view(torch.int64))
+        self.frames_host, self.speed_host, self.cmd_host = views(self.in_host)
+        self.frames_dev, self.speed_dev, self.cmd_dev = views(self.in_dev)
+        self.out_dev = torch.empty(batch * 4, dtype=torch.float32, device=dev)
+        self.out_host = torch.empty(batch * 4, dtype=torch.float32).pin_memory()
+        self.ctrl_dev = self.out_dev[:batch * 3].view(batch, 3)
+        self.spd_out_dev = self.out_dev[batch * 3:]
+        self._ctrl_np = self.out_host[:batch * 3].view(batch, 3).numpy()
+        self._spd_np = self.out_host[batch * 3:].numpy()
         self._frames_np = self.frames_host.numpy()
         self._speed_np = self.speed_host.numpy()
         self._cmd_np = self.cmd_host.numpy()
+        self._seen_epoch = -1
 
-    def _raise_on_status(self):
-        # the status words ride along with the outputs' device->host copy: a command outside
-        # 0..3 raises here exactly where the reference's torch.gather does (:397-398, :915-917)
-        if self._status_np[0] != 0:
+    def _order_after_weight_updates(self):
+        # The forward runs on this predictor's own stream.  Whatever last wrote the weights (a
+        # train step, load_state_dict, an optimiser) was enqueued on the caller's current stream:
+        # order this stream behind it -- only when the engine's weight epoch moved, so the
+        # steady-state control loop pays nothing.
+        if self._seen_epoch != self.eng.weights_epoch:
+            self.stream.wait_stream(torch.cuda.current_stream(self.eng.device))
+            self._seen_epoch = self.eng.weights_epoch
+
+    @staticmethod
+    def _check_commands(commands):
+        # the command comes from the host (route planner, autonomous_drive.py:1589-1593): validate
+        # it here -- a value outside 0..3 raises exactly where the reference's torch.gather does
+        # (:397-398, :915-917), without waiting for the device's status word
+        c = np.asarray(commands, dtype=np.int64)
+        if c.size and (c.min() < 0 or c.max() > 3):
             raise RuntimeError("predict_controls: command index out of range (expected 0..3)")
+        return c
 
     @torch.no_grad()
     def predict_batch(self, frames_u8, speeds_kmh, commands):
@@ -76,20 +96,15 @@ class Predictor:
         # min(speed_kmh / 90.0, 1.0) in double like the reference (:910), then float32
         self._speed_np[...] = np.minimum(
             np.asarray(speeds_kmh, dtype=np.float64) / SPEED_NORM_FACTOR, 1.0)
-        np.copyto(self._cmd_np, np.asarray(commands, dtype=np.int64))
+        np.copyto(self._cmd_np, self._check_commands(commands))
+        self._order_after_weight_updates()
         with torch.cuda.stream(self.stream):
-            self.frames_dev.copy_(self.frames_host, non_blocking=True)
-            self.speed_dev.copy_(self.speed_host, non_blocking=True)
-            self.cmd_dev.copy_(self.cmd_host, non_blocking=True)
+            self.in_dev.copy_(self.in_host, non_blocking=True)
             self.eng.run_forward_u8(self.frames_dev, self.speed_dev, self.cmd_dev,
                                     out=(self.ctrl_dev, self.spd_out_dev), graph=self.use_graph,
                                     half=self.half)
-            # two tiny D2H copies into pinned memory; no torch kernels, no allocations
-            self.ctrl_host.copy_(self.ctrl_dev, non_blocking=True)
-            self.spd_out_host.copy_(self.spd_out_dev, non_blocking=True)
-            self.status_host.copy_(self.eng.last_plan.status, non_blocking=True)
+            self.out_host.copy_(self.out_dev, non_blocking=True)     # pinned; no torch kernels
             self.stream.synchronize()
-        self._raise_on_status()
         out = np.empty((self.batch, 4), dtype=np.float32)
         out[:, :3] = self._ctrl_np
         out[:, 3] = self._spd_np * np.float32(SPEED_NORM_FACTOR)                # :920
@@ -110,25 +125,29 @@ class Predictor:
         if self.model.training:
             self.model.eval()
         cam = getattr(self, "_cam", None)
-        if cam is None or cam[0].shape[1:] != frame.shape:
-            host = torch.empty((1,) + frame.shape, dtype=torch.uint8).pin_memory()
-            cam = (host, host.numpy(), torch.empty_like(host, device=self.eng.device))
+        if cam is None or cam[3] != frame.shape:
+            nfr = frame.size
+            o_spd = (nfr + 15) // 16 * 16
+            host = torch.zeros(o_spd + 16, dtype=torch.uint8).pin_memory()
+            dev = torch.zeros_like(host, device=self.eng.device)
+
+            def views(buf):
+                return (buf[:nfr].view((1,) + frame.shape), buf[o_spd:o_spd + 4].view(torch.float32),
+                        buf[o_spd + 8:o_spd + 16].view(torch.int64))
+            hv, dv = views(host), views(dev)
+            cam = (host, (hv[0].numpy(), hv[1].numpy(), hv[2].numpy()), (dev,) + dv, frame.shape)
             self._cam = cam
-        np.copyto(cam[1][0], frame)
-        self._speed_np[...] = min(float(speed_kmh) / SPEED_NORM_FACTOR, 1.0)
-        self._cmd_np[...] = int(command_idx)
+        np.copyto(cam[1][0][0], frame)
+        cam[1][1][...] = min(float(speed_kmh) / SPEED_NORM_FACTOR, 1.0)
+        cam[1][2][...] = self._check_commands([int(command_idx)])
+        self._order_after_weight_updates()
         with torch.cuda.stream(self.stream):
-            cam[2].copy_(cam[0], non_blocking=True)
-            self.speed_dev.copy_(self.speed_host, non_blocking=True)
-            self.cmd_dev.copy_(self.cmd_host, non_blocking=True)
-            self.eng.run_forward_camera(cam[2], self.speed_dev, self.cmd_dev,
+            cam[2][0].copy_(cam[0], non_blocking=True)               # frame | speed | command
+            self.eng.run_forward_camera(cam[2][1], cam[2][2], cam[2][3],
                                         self.frames_host.size(1), self.frames_host.size(2),
                                         out=(self.ctrl_dev, self.spd_out_dev))
-            self.ctrl_host.copy_(self.ctrl_dev, non_blocking=True)
-            self.spd_out_host.copy_(self.spd_out_dev, non_blocking=True)
-            self.status_host.copy_(self.eng.last_plan.status, non_blocking=True)
+            self.out_host.copy_(self.out_dev, non_blocking=True)
             self.stream.synchronize()
-        self._raise_on_status()
         c = self._ctrl_np[0]
         return (float(c[0]), float(c[1]), float(c[2]), float(self._spd_np[0]) * SPEED_NORM_FACTOR)
 

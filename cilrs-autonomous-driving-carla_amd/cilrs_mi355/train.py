@@ -117,6 +117,7 @@ class Trainer:
                                           self._stream()))
             clip_ptr = L.ptr(self.clip_out)
         self.step_count += 1
+        eng.weights_epoch += 1                # the fused Adam writes the parameter arena in place
         L.check(lib.cilrs_adam_step(L.ptr(eng.params), L.ptr(eng.grads), L.ptr(self.exp_avg),
                                     L.ptr(self.exp_avg_sq), eng.n_arena, self.lr, cfg.betas[0],
                                     cfg.betas[1], cfg.eps, cfg.weight_decay, self.step_count,

@@ -280,6 +280,14 @@ struct cilrs_net {
     const void* graph_key[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                                 nullptr};
     bool warmed = false;
+    // Weight-derived inference state cached across calls: eval-mode BatchNorm scale/shift of every
+    // layer + the channel-padded stem weights (prep_key), and the 16-bit folded weights / biases
+    // (fold_key, fold_half).  Valid while the caller's weights key (cilrs_net_set_weights_key:
+    // "parameters and BN buffers are unchanged while this value stays the same"; 0 = unknown,
+    // never cache) and the buffers are the ones the state was computed from.
+    uint64_t weights_key = 0, prep_key = 0, fold_key = 0, graph_wkey = 0;
+    int fold_half = 0;
+    const void* prep_bufs[3] = {nullptr, nullptr, nullptr};     // params, bn_running, workspace
     bool trained_fwd = false;
     float last_dropout = 0.f;
     Prof prof;
@@ -725,6 +733,12 @@ void cilrs_net_destroy(cilrs_net* net) {
 size_t cilrs_net_workspace_bytes(const cilrs_net* net) { return net ? net->ws_bytes : 0; }
 size_t cilrs_net_status_offset(const cilrs_net* net) { return net ? net->status_b : 0; }
 
+int cilrs_net_set_weights_key(cilrs_net* net, uint64_t key) {
+    CILRS_CHECK(net != nullptr, "set_weights_key: net is NULL");
+    net->weights_key = key;
+    return 0;
+}
+
 int cilrs_dropout(float* a, int rows, int cols, int ld, float p, uint64_t seed, int site,
                   void* stream) {
     CILRS_CHECK(a && rows >= 1 && cols >= 1 && ld >= cols && site >= 0 && site <= 9,
@@ -769,8 +783,15 @@ static int forward_from_x4(cilrs_net* net, const cilrs_buffers* bufs, const floa
     };
 
     // ---- stem: conv7x7/s2 + BN + ReLU + maxpool3x3/s2 ----
-    RUN(net, "transform", 0.0, 0.0, s,
-        launch_pad_cin3_to_4(P + A.convs[0].w, ws + net->w4, 64 * 49, s));
+    const bool same_bufs = net->prep_bufs[0] == (const void*)bufs->params &&
+                           net->prep_bufs[1] == (const void*)bufs->bn_running &&
+                           net->prep_bufs[2] == (const void*)bufs->workspace;
+    const bool prep_cached = !train && net->weights_key != 0 && same_bufs &&
+                             net->prep_key == net->weights_key;
+    if (!prep_cached)
+        RUN(net, "transform", 0.0, 0.0, s,
+            launch_pad_cin3_to_4(P + A.convs[0].w, ws + net->w4, 64 * 49, s));
+    if (train) { net->prep_key = 0; net->fold_key = 0; }     // weights / BN buffers are about to change
     const float* cur;
     if (train) {
         int nb = 0;                             // batch statistics fused into the conv epilogue
@@ -821,8 +842,14 @@ static int forward_from_x4(cilrs_net* net, const cilrs_buffers* bufs, const floa
     } else {
         // eval: running statistics -> per-channel scale/shift (one launch for all 36 layers),
         // folded with ReLU / residual add into each conv's epilogue; no pre-BN tensor is stored
-        RUN(net, "bn_fwd.eval", 0.0, 0.0, s,
-            launch_bn_eval_stats_all(net->bn_table, P, R, ws, eps, s));
+        if (!prep_cached) {
+            RUN(net, "bn_fwd.eval", 0.0, 0.0, s,
+                launch_bn_eval_stats_all(net->bn_table, P, R, ws, eps, s));
+            net->prep_key = net->weights_key;
+            net->prep_bufs[0] = bufs->params; net->prep_bufs[1] = bufs->bn_running;
+            net->prep_bufs[2] = bufs->workspace;
+            net->fold_key = 0;
+        }
         if (conv_fwd(net, A.convs[0], net->cg[0], ws + net->x4, 4, ws + net->w4,
                      ws + net->cg[0].z, ws, s, nullptr, ws + net->cg[0].stats, 1)) return 1;
         RUN(net, "maxpool", 0.0, 4.0 * net->cg[0].M * 64 * 1.25, s,
@@ -837,8 +864,14 @@ static int forward_from_x4(cilrs_net* net, const cilrs_buffers* bufs, const floa
             const int bf16 = half == 2;
             cilrs_half* act[5];
             for (int k = 0; k < 5; ++k) act[k] = reinterpret_cast<cilrs_half*>(ws + net->f16_act[k]);
-            RUN(net, "transform", 0.0, 0.0, s,
-                launch_fold_bn_f16(net->f16_table, P, ws, w16, b16, bf16, s));
+            const bool fold_cached = net->weights_key != 0 && net->fold_key == net->weights_key &&
+                                     net->fold_half == half && prep_cached;
+            if (!fold_cached) {
+                RUN(net, "transform", 0.0, 0.0, s,
+                    launch_fold_bn_f16(net->f16_table, P, ws, w16, b16, bf16, s));
+                net->fold_key = net->weights_key;
+                net->fold_half = half;
+            }
             RUN(net, "transform", 0.0, 0.0, s,
                 launch_f32_to_f16(ws + net->pool, act[0], (size_t)B * net->H1 * net->W1 * 64, bf16,
                                   s));
@@ -1130,10 +1163,14 @@ static int forward_u8_graph(cilrs_net* net, const cilrs_buffers* bufs, const uin
     CILRS_CHECK(s != nullptr, "forward_u8_graph: capture needs a non-default stream");
     const void* key[8] = {bufs->params, bufs->bn_running, bufs->workspace, frames, speed, command,
                           controls, pred_speed};
-    bool same = net->graph_exec != nullptr && net->graph_half == half;
+    bool same = net->graph_exec != nullptr && net->graph_half == half &&
+                net->graph_wkey == net->weights_key;
     for (int i = 0; i < 8 && same; ++i) same = key[i] == net->graph_key[i];
     if (!same) {
-        if (!net->warmed) {      // first call eager: function attributes, side streams, events
+        // first call eager: function attributes, side streams, events; and whenever the weights
+        // key moved, so that the weight-derived state is rebuilt OUTSIDE the capture and the graph
+        // holds only the per-frame kernels
+        if (!net->warmed || net->prep_key != net->weights_key || net->weights_key == 0) {
             if (ensure_streams(net)) return 1;
             if (eager(net, bufs, frames, speed, command, controls, pred_speed, stream)) return 1;
             CILRS_HIP(hipStreamSynchronize(s));
@@ -1155,6 +1192,7 @@ static int forward_u8_graph(cilrs_net* net, const cilrs_buffers* bufs, const uin
         CILRS_CHECK(e2 == hipSuccess, "hipGraphInstantiate failed: %s", hipGetErrorString(e2));
         for (int i = 0; i < 8; ++i) net->graph_key[i] = key[i];
         net->graph_half = half;
+        net->graph_wkey = net->weights_key;
     }
     CILRS_HIP(hipGraphLaunch(net->graph_exec, s));
     return 0;

@@ -102,6 +102,16 @@ int cilrs_net_forward(cilrs_net* net, const cilrs_buffers* bufs, const float* im
  * (Predictor: with the outputs; Trainer.losses() / validate()) and raises like torch does. */
 size_t cilrs_net_status_offset(const cilrs_net* net);
 
+/* Inference between weight updates (the control loop, autonomous_drive.py:908-920, calls forward
+ * once per simulator tick on weights loaded once, :496-498): a promise by the caller that the
+ * parameter arena and the BatchNorm buffers are unchanged for as long as `key` keeps its value.
+ * The plan then keeps what it derives from them -- every layer's eval-mode BatchNorm scale/shift,
+ * the channel-padded stem weights, the 16-bit folded weights -- instead of recomputing it on
+ * every eval forward (two to three launches per frame).  key 0 (the default) = no promise.
+ * The Python mirror derives the key from the arenas' torch version counters plus a counter it
+ * bumps on every train-mode forward and optimiser step. */
+int cilrs_net_set_weights_key(cilrs_net* net, uint64_t key);
+
 /* nn.Dropout(p) in training mode exactly as the fused heads apply it (inverted dropout, keep
  * where hash(seed, site, row * cols + col) >= p, kept values divided by 1 - p), in place over
  * a [rows][cols] matrix with row pitch ld.  `site` names the Dropout module:

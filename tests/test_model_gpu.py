@@ -1003,3 +1003,51 @@ def test_bf16_trunk_on_the_reference_network():
     eng = m.engine()
     cb, sb = eng.run_forward_u8(torch.from_numpy(u8).cuda(), spd.cuda(), cmd.cuda(), half="bf16")
     assert (cb.cpu() - oc).abs().max() <= TOL_BF16 and (sb.cpu() - os_).abs().max() <= TOL_BF16
+
+
+def test_inference_state_cache_follows_weight_updates():
+    """The plan keeps what it derives from the weights for inference (eval-mode BatchNorm
+    scale/shift, padded stem weights, 16-bit folded weights) between calls; every way the weights
+    can change must invalidate it: load_state_dict, a fused train step, a torch.optim step through
+    the autograd bridge, and CILRS.weights_changed() after a raw in-place edit -- on the eager and
+    the hipGraph paths, fp32 and fp16."""
+    from cilrs_mi355 import CONFIG_A, Trainer
+    from cilrs_mi355.predict import Predictor
+    frame = np.floor(O._hash_u01(3, 9, 88 * 200 * 3) * 256).astype(np.uint8).reshape(88, 200, 3)
+    imgs, spds, cmds, tgts = to_dev(*O.synthetic_batch(4, seed=13)[:4])
+
+    def fresh_answer(state, half):
+        m2 = make_model()
+        m2.load_state_dict(state, strict=True)
+        return Predictor(m2, half=half).predict_controls(frame, 30.0, 1)
+
+    for use_graph in (False, True):
+        for half in (False, True):
+            m = make_model()
+            pr = Predictor(m, use_graph=use_graph, half=half)
+            a0 = pr.predict_controls(frame, 30.0, 1)
+            assert pr.predict_controls(frame, 30.0, 1) == a0              # cached path == first call
+            assert a0 == fresh_answer(m.state_dict(), half)
+            # 1. load_state_dict with other weights
+            m.load_state_dict(O.portable_state_dict(m.state_dict(), 7), strict=True)
+            a1 = pr.predict_controls(frame, 30.0, 1)
+            assert a1 != a0 and a1 == fresh_answer(m.state_dict(), half)
+            # 2. a fused train step (parameters AND BatchNorm running statistics move)
+            tr = Trainer(m, CONFIG_A)
+            tr.train_step(imgs, spds, cmds, tgts)
+            a2 = pr.predict_controls(frame, 30.0, 1)
+            assert a2 != a1 and a2 == fresh_answer(m.state_dict(), half)
+            # 3. torch.optim over model.parameters() through the autograd bridge
+            m.train()
+            opt = torch.optim.SGD(m.parameters(), lr=0.05)
+            pc, ps = m(imgs, spds, cmds)
+            (pc.square().mean() + ps.square().mean()).backward()
+            opt.step()
+            a3 = pr.predict_controls(frame, 30.0, 1)
+            assert a3 != a2 and a3 == fresh_answer(m.state_dict(), half)
+            # 4. raw in-place edit in eval mode + the explicit notification
+            with torch.no_grad():
+                m.speed_predictor[5].bias.add_(0.25)
+            m.weights_changed()
+            a4 = pr.predict_controls(frame, 30.0, 1)
+            assert abs((a4[3] - a3[3]) - 0.25 * 90.0) <= 1e-3 and a4[:3] == a3[:3]
