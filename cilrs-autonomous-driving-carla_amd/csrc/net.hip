@@ -921,8 +921,12 @@ static int forward_from_x4(cilrs_net* net, const cilrs_buffers* bufs, const floa
         auto conv_eval = [&](const ConvT& c, const ConvG& g, const float* x, float* y, int relu,
                              const float* addend, int relu_post) -> int {
             // one 16-wave block per 16x16 tile: worth it while every block gets its own CU
-            if (cdiv(g.M, 16) * (c.cout / 16) > kSmallConvBlocks || c.cin % 16 != 0 ||
-                c.k * c.k * c.cin > kSmallConvK)
+            // CILRS_SMALL_BLOCKS / CILRS_SMALL_K: routing thresholds for tools/infer_ab.py
+            static const int max_blocks =
+                getenv("CILRS_SMALL_BLOCKS") ? atoi(getenv("CILRS_SMALL_BLOCKS")) : kSmallConvBlocks;
+            static const int max_k = getenv("CILRS_SMALL_K") ? atoi(getenv("CILRS_SMALL_K")) : kSmallConvK;
+            if (cdiv(g.M, 16) * (c.cout / 16) > max_blocks || c.cin % 16 != 0 ||
+                c.k * c.k * c.cin > max_k)
                 return conv_fwd(net, c, g, x, c.cin, P + c.w, y, ws, s, nullptr, ws + g.stats,
                                 relu, addend, relu_post);
             ConvSmallArgs a;
