@@ -14,6 +14,8 @@
 // taps read zeros), LDS double buffer with a 72-half pitch (conflict-free ds_read_b128).
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace cilrs {
 namespace {
 
@@ -21,7 +23,7 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef __bf16 b8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half_t;      // storage type of the shared 16-bit buffers (bit container)
 
-constexpr int HBM = 64, HBN = 64, HBK = 64, HPITCH = 72;     // halfs
+constexpr int HBK = 64, HPITCH = 72;     // halfs: K-tile, LDS row pitch
 
 template <typename T> struct Vec8;
 template <> struct Vec8<_Float16> { typedef h8 type; };
@@ -33,26 +35,46 @@ __device__ __forceinline__ f32x16 mfma16(const b8 a, const b8 b, const f32x16 c)
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
-template <typename T>
-__global__ __launch_bounds__(256, 2) void conv_f16_kernel(const ConvF16Args a) {
+// BMxBN output tile per 256-thread block, 4 waves as 2x2, each wave (BM/64) x (BN/64) MFMA tiles:
+//   64x64   one 32x32 accumulator per wave, 36 KB LDS, four blocks per CU -- layers with few output
+//           pixels (many small blocks beat a handful of big ones);
+//   128x128 four accumulators per wave, 72 KB LDS, two blocks per CU -- a quarter of the global
+//           loads, LDS writes and address work per MFMA.  Measured on MI355X it LOSES on every
+//           layer of both networks at B=64 (ResNet-50 variant 4.74 vs 3.68 ms per batch, ResNet-34
+//           fp16 1.48 vs 0.92 ms): these convolutions have 1-18 K-tiles per block and are bound
+//           by memory-level parallelism, which two fat blocks per CU halve.  Opt-in only
+//           (CILRS_F16_TILE=128).
+template <typename T, int BM, int BN>
+__global__ __launch_bounds__(256, (BM == 64 ? 2 : 2)) void conv_f16_kernel(const ConvF16Args a) {
     typedef typename Vec8<T>::type v8;
-    __shared__ __attribute__((aligned(16))) T As[2][HBM * HPITCH];
-    __shared__ __attribute__((aligned(16))) T Bs[2][HBN * HPITCH];
+    constexpr int TM = BM / 64, TN = BN / 64;          // MFMA tiles per wave
+    constexpr int AP = BM / 32, BP = BN / 32;          // 32-row load passes per K-tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* As = reinterpret_cast<T*>(smem_raw);                        // [2][BM][HPITCH]
+    T* Bs = As + 2 * BM * HPITCH;                                  // [2][BN][HPITCH]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
-    const int tilesN = a.Cout / HBN;
-    const int m0 = (blockIdx.x / tilesN) * HBM, n0 = (blockIdx.x % tilesN) * HBN;
+    const int tilesN = a.Cout / BN;
+    // XCD-aware block order: consecutive ids go round-robin over the 8 XCDs; give each XCD a
+    // contiguous run of tiles so neighbouring tiles (shared rows / weights) share an L2
+    int logical;
+    {
+        const int nwg = (int)gridDim.x, bid = (int)blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int m0 = (logical / tilesN) * BM, n0 = (logical % tilesN) * BN;
     const int M = a.N * a.Ho * a.Wo, HoWo = a.Ho * a.Wo;
     const int ntaps = a.K * a.K, cin_tiles = a.Cin / HBK;
     const int nt = ntaps * cin_tiles;
     const long Krow = (long)ntaps * a.Cin;
 
-    // per-thread gather rows: rows r0 and r0 + 32, 16-byte chunk kq of the 128-byte K-tile row
+    // per-thread gather rows: rows r0 + 32 i, 16-byte chunk kq of the 128-byte K-tile row
     const int kq = tid & 7, r0 = tid >> 3;
-    unsigned rowOff[2], rowMask[2], wOff[2];
+    unsigned rowOff[AP], rowMask[AP], wOff[BP];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < AP; ++i) {
         const int m = m0 + r0 + 32 * i;
         rowMask[i] = 0u;
         rowOff[i] = 0u;
@@ -66,8 +88,10 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const ConvF16Args a) {
                 if (h >= 0 && w >= 0 && h < a.H && w < a.W) rowMask[i] |= 1u << t;
             }
         }
-        wOff[i] = (unsigned)(((long)(n0 + r0 + 32 * i) * Krow + kq * 8) * 2);
     }
+#pragma unroll
+    for (int i = 0; i < BP; ++i)
+        wOff[i] = (unsigned)(((long)(n0 + r0 + 32 * i) * Krow + kq * 8) * 2);
     int tapA_v = 0, tapB_v = 0;              // per-tap byte offsets, one tap per lane
     if (lane < ntaps) {
         tapA_v = ((lane / a.K) * a.W + lane % a.K) * a.Cin * 2;
@@ -79,43 +103,58 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const ConvF16Args a) {
         __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, -1, 0x00020000);
 
     int ld_tap = 0, ld_c = 0;
-    auto load_tile = [&](f32x4(&ra)[2], f32x4(&rb)[2]) {
+    auto load_tile = [&](f32x4(&ra)[AP], f32x4(&rb)[BP]) {
         const unsigned toff = (unsigned)__builtin_amdgcn_readlane(tapA_v, ld_tap) +
                               (unsigned)(ld_c * HBK * 2);
         const unsigned koff = (unsigned)__builtin_amdgcn_readlane(tapB_v, ld_tap) +
                               (unsigned)(ld_c * HBK * 2);
         const unsigned bit = 1u << ld_tap;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < AP; ++i) {
             const unsigned off = (rowMask[i] & bit) ? rowOff[i] + toff : 0xFFFFFFFFu;
             ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)off, 0, 0));
+        }
+#pragma unroll
+        for (int i = 0; i < BP; ++i)
             rb[i] = __builtin_bit_cast(
                 f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)(wOff[i] + koff), 0, 0));
-        }
         if (++ld_c == cin_tiles) { ld_c = 0; ++ld_tap; }
     };
-    auto store_tile = [&](int buf, const f32x4(&ra)[2], const f32x4(&rb)[2]) {
+    auto store_tile = [&](int buf, const f32x4(&ra)[AP], const f32x4(&rb)[BP]) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            *reinterpret_cast<f32x4*>(&As[buf][(r0 + 32 * i) * HPITCH + kq * 8]) = ra[i];
-            *reinterpret_cast<f32x4*>(&Bs[buf][(r0 + 32 * i) * HPITCH + kq * 8]) = rb[i];
-        }
+        for (int i = 0; i < AP; ++i)
+            *reinterpret_cast<f32x4*>(&As[(buf * BM + r0 + 32 * i) * HPITCH + kq * 8]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BP; ++i)
+            *reinterpret_cast<f32x4*>(&Bs[(buf * BN + r0 + 32 * i) * HPITCH + kq * 8]) = rb[i];
     };
-    f32x16 acc;
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     auto compute = [&](int buf) {
-        const T* Ab = &As[buf][(wm * 32 + l31) * HPITCH + lh * 8];
-        const T* Bb = &Bs[buf][(wn * 32 + l31) * HPITCH + lh * 8];
+        const T* Ab = &As[(buf * BM + wm * (BM / 2) + l31) * HPITCH + lh * 8];
+        const T* Bb = &Bs[(buf * BN + wn * (BN / 2) + l31) * HPITCH + lh * 8];
 #pragma unroll
         for (int q = 0; q < HBK / 16; ++q) {
-            const v8 av = *reinterpret_cast<const v8*>(Ab + q * 16);
-            const v8 bv = *reinterpret_cast<const v8*>(Bb + q * 16);
-            acc = mfma16(av, bv, acc);
+            v8 av[TM], bv[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                av[i] = *reinterpret_cast<const v8*>(Ab + i * 32 * HPITCH + q * 16);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bv[j] = *reinterpret_cast<const v8*>(Bb + j * 32 * HPITCH + q * 16);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = mfma16(av[i], bv[j], acc[i][j]);
         }
     };
 
-    f32x4 ra0[2], rb0[2], ra1[2], rb1[2];
+    f32x4 ra0[AP], rb0[BP], ra1[AP], rb1[BP];
     int it = 0;
     if (nt >= 4) {
         load_tile(ra0, rb0);
@@ -153,18 +192,24 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const ConvF16Args a) {
     }
 
     // ---- epilogue: + folded-BN bias (+ 16-bit residual), ReLU, 16-bit store --------------------
-    const int co = n0 + wn * 32 + l31;
-    const float bias = a.bias[co];
     const T* res = reinterpret_cast<const T*>(a.residual);
     T* yout = reinterpret_cast<T*>(a.y);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m >= M) continue;
-        float v = acc[r] + bias;
-        if (res) v += (float)res[(size_t)m * a.Cout + co];
-        if (a.relu) v = fmaxf(v, 0.f);
-        yout[(size_t)m * a.Cout + co] = (T)v;
+    for (int j = 0; j < TN; ++j) {
+        const int co = n0 + wn * (BN / 2) + j * 32 + l31;
+        const float bias = a.bias[co];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= M) continue;
+                float v = acc[i][j][r] + bias;
+                if (res) v += (float)res[(size_t)m * a.Cout + co];
+                if (a.relu) v = fmaxf(v, 0.f);
+                yout[(size_t)m * a.Cout + co] = (T)v;
+            }
+        }
     }
 }
 
@@ -222,16 +267,33 @@ __global__ __launch_bounds__(256) void avgpool_f16_kernel(const T* __restrict__ 
 
 }  // namespace
 
+template <typename T, int BM, int BN>
+static int launch_conv_f16_cfg(const ConvF16Args& a, int M, hipStream_t s) {
+    constexpr size_t lds = (size_t)2 * (BM + BN) * HPITCH * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        CILRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f16_kernel<T, BM, BN>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    conv_f16_kernel<T, BM, BN><<<cdiv(M, BM) * (a.Cout / BN), 256, lds, s>>>(a);
+    CILRS_LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_conv_f16(const ConvF16Args& a, hipStream_t s) {
-    CILRS_CHECK(a.Cin % HBK == 0 && a.Cout % HBN == 0 && a.K * a.K <= 16,
+    CILRS_CHECK(a.Cin % HBK == 0 && a.Cout % 64 == 0 && a.K * a.K <= 16,
                 "conv_f16: Cin %% 64, Cout %% 64, <= 16 taps");
     CILRS_CHECK((size_t)a.N * a.H * a.W * a.Cin * 2 < (1ull << 32), "conv_f16: input too large");
     const int M = a.N * a.Ho * a.Wo;
-    const int grid = cdiv(M, HBM) * (a.Cout / HBN);
-    if (a.bf16) conv_f16_kernel<__bf16><<<grid, 256, 0, s>>>(a);
-    else conv_f16_kernel<_Float16><<<grid, 256, 0, s>>>(a);
-    CILRS_LAUNCH_CHECK();
-    return 0;
+    // 64x64 tiles everywhere (see the kernel's header); CILRS_F16_TILE=128 forces the big tile
+    static const int force = getenv("CILRS_F16_TILE") ? atoi(getenv("CILRS_F16_TILE")) : 0;
+    const bool big = a.Cout % 128 == 0 && force == 128;
+    if (big)
+        return a.bf16 ? launch_conv_f16_cfg<__bf16, 128, 128>(a, M, s)
+                      : launch_conv_f16_cfg<_Float16, 128, 128>(a, M, s);
+    return a.bf16 ? launch_conv_f16_cfg<__bf16, 64, 64>(a, M, s)
+                  : launch_conv_f16_cfg<_Float16, 64, 64>(a, M, s);
 }
 
 int launch_fold_bn_f16(const FoldF16Table& t, const float* params, const float* ws, void* w16,
