@@ -113,3 +113,28 @@ def load(path, model, trainer=None, map_location=None):
         if "scheduler_state_dict" in ck:
             trainer.epoch = int(ck["scheduler_state_dict"]["last_epoch"])
     return ck
+
+
+# torchvision.models.resnet34 children in order (conv1, bn1, relu, maxpool, layer1..4, avgpool, fc):
+# the reference drops fc and wraps the rest in nn.Sequential (autonomous_drive.py:366-370), so child
+# i becomes ``visual_encoder.i``
+_TV_CHILD = {"conv1": 0, "bn1": 1, "layer1": 4, "layer2": 5, "layer3": 6, "layer4": 7}
+
+
+def trunk_state_from_torchvision(resnet_state_dict):
+    """Re-key a ``torchvision.models.resnet34().state_dict()`` (e.g. the ImageNet weights the
+    executed notebook starts from, ``ResNet34_Weights.DEFAULT``, notebook/notebook.ipynb:444) the
+    way the reference's ``nn.Sequential(*list(resnet.children())[:-1])`` does:
+    ``conv1.weight -> visual_encoder.0.weight``, ``layer2.0.bn1.bias -> visual_encoder.5.0.bn1.bias``
+    ...; ``fc.*`` is dropped.  Use with ``model.load_state_dict(sd, strict=False)`` (the heads keep
+    their initialisation), exactly what constructing the reference class with pretrained weights
+    amounts to.  Also works for the ResNet-50 variant (same child order)."""
+    out = {}
+    for k, v in resnet_state_dict.items():
+        head, _, rest = k.partition(".")
+        if head == "fc":
+            continue
+        if head not in _TV_CHILD:
+            raise KeyError(f"unexpected torchvision ResNet key {k!r}")
+        out[f"visual_encoder.{_TV_CHILD[head]}.{rest}"] = v
+    return out

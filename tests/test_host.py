@@ -528,3 +528,22 @@ def test_resnet50_variant_layout_matches_its_oracle():
     assert _layout(0)[0][:3] == _layout()[0][:3]
     with pytest.raises(RuntimeError):
         m.train()(torch.zeros(1, 3, 176, 400), torch.zeros(1), torch.zeros(1, dtype=torch.long))
+
+
+def test_torchvision_trunk_keys_map_onto_the_reference_wrapping():
+    """ImageNet-pretrained start of the executed notebook (nb:444): a torchvision-keyed ResNet-34
+    state_dict (the oracle's trunk carries torchvision's attribute names) re-keyed by
+    checkpoint.trunk_state_from_torchvision loads into CILRS.visual_encoder completely."""
+    from cilrs_mi355 import CILRS, checkpoint
+    tv = O.ResNet34Trunk()                                  # torchvision's names incl. fc
+    sd = checkpoint.trunk_state_from_torchvision(tv.state_dict())
+    m = CILRS(4, 0.0)
+    want = {k for k in m.state_dict() if k.startswith("visual_encoder.")}
+    assert set(sd) == want and not any(k.startswith("visual_encoder.9") for k in sd)
+    res = m.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys
+    assert all(not k.startswith("visual_encoder.") for k in res.missing_keys)
+    assert torch.equal(m.state_dict()["visual_encoder.5.0.downsample.0.weight"],
+                       tv.state_dict()["layer2.0.downsample.0.weight"])
+    with pytest.raises(KeyError):
+        checkpoint.trunk_state_from_torchvision({"stem.weight": torch.zeros(1)})
