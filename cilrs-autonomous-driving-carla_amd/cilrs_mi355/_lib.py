@@ -71,6 +71,7 @@ SIGNATURES = {
     "cilrs_loss_fwd_bwd": (i32, [vp, vp, vp, vp, i32, i32, c_float_p, f32, vp, vp, vp, vp]),
     "cilrs_net_backward": (i32, [vp, C.POINTER(Buffers), vp, vp, i32, i32, vp]),
     "cilrs_segment_range": (i32, [i32, C.POINTER(sz), C.POINTER(sz)]),
+    "cilrs_variant_segment_range": (i32, [i32, i32, C.POINTER(sz), C.POINTER(sz)]),
     "cilrs_sqnorm_scratch_bytes": (sz, []),
     "cilrs_grad_sqnorm": (i32, [vp, sz, f32, vp, vp, vp]),
     "cilrs_adam_step": (i32, [vp, vp, vp, vp, sz, f64, f64, f64, f64, f64, i64, vp, f32, vp]),

@@ -47,13 +47,13 @@ def _layout(variant=0):
     return params, bns
 
 
-def segment_ranges():
+def segment_ranges(variant=0):
     """[(begin, end)] float ranges of the gradient arena, in backward execution order."""
     lib = L.lib()
     out = []
     for s in range(6):
         b, e = L.sz(), L.sz()
-        L.check(lib.cilrs_segment_range(s, C.byref(b), C.byref(e)))
+        L.check(lib.cilrs_variant_segment_range(variant, s, C.byref(b), C.byref(e)))
         out.append((b.value, e.value))
     return out
 

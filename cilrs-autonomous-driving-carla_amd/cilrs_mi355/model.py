@@ -172,8 +172,9 @@ class CILRSResNet50(CILRS):
     Linear of every branch is 2176 wide and the speed predictor's 2048 wide).  The reference has
     no such model (model/autonomous_drive.py:365 is resnet34 only); state_dict keys follow the
     same re-wrapping (visual_encoder.{4..7}.{blk}.{conv1,bn1,conv2,bn2,conv3,bn3,downsample}).
-    Inference only: eval-mode forward in fp32, or through Engine.run_forward_u8(half="bf16")
-    with the trunk on the bf16 matrix pipe."""
+    Trains in fp32 through the same HIP kernels as the reference network (train-mode forward,
+    backward, Trainer); inference in fp32, or through Engine.run_forward_u8(half="bf16") with the
+    trunk on the bf16 matrix pipe."""
     VARIANT = 1
     FEATURES = 2048
 
@@ -184,9 +185,3 @@ class CILRSResNet50(CILRS):
             _make_bottleneck_layer(64, 64, 3, 1), _make_bottleneck_layer(256, 128, 4, 2),
             _make_bottleneck_layer(512, 256, 6, 2), _make_bottleneck_layer(1024, 512, 3, 2),
             nn.AdaptiveAvgPool2d((1, 1)), nn.Flatten())
-
-    def forward(self, image, speed, command):
-        if self.training:
-            raise RuntimeError("CILRSResNet50 is an inference-only variant: call .eval() first "
-                               "(the HIP engine has no ResNet-50 training path)")
-        return super().forward(image, speed, command)

@@ -32,11 +32,11 @@ def bucket_plan(seg_ranges):
 
 
 class BucketedAllReduce:
-    def __init__(self, flat_grads: torch.Tensor, process_group=None, buckets=None):
+    def __init__(self, flat_grads: torch.Tensor, process_group=None, buckets=None, variant=0):
         self.flat = flat_grads
         self.pg = process_group if process_group is not None else dist.group.WORLD
         self.world_size = dist.get_world_size(self.pg)
-        self.buckets = buckets if buckets is not None else bucket_plan(segment_ranges())
+        self.buckets = buckets if buckets is not None else bucket_plan(segment_ranges(variant))
         self._pending = []
 
     def reduce_bucket(self, i):

@@ -71,7 +71,8 @@ class Trainer:
         if process_group is not None:
             import torch.distributed as dist
             from .parallel import BucketedAllReduce
-            self.reducer = BucketedAllReduce(self.eng.grads, process_group)
+            self.reducer = BucketedAllReduce(self.eng.grads, process_group,
+                                             variant=self.eng.variant)
             self.rank = dist.get_rank(process_group)
 
     # -- pieces ---------------------------------------------------------------------------------

@@ -27,7 +27,11 @@ __global__ __launch_bounds__(256) void bn_colreduce_kernel(
     const float* __restrict__ stats, float* __restrict__ partial, const int M, const int C,
     const int relu, const int rows_per_block) {
     __shared__ float red[2][256 * 4];
-    const int cq = C >> 2;                 // float4 quads per row (16..128)
+    // rows wider than 1,024 channels (the Bottleneck variant's 2,048) are cut into column groups
+    // of 1,024: blockIdx.y = group, one float4 per thread per row as before
+    const int Cg = C > 1024 ? 1024 : C;    // channels this block covers
+    const int c0 = blockIdx.y * Cg;
+    const int cq = Cg >> 2;                // float4 quads per row (16..256)
     const int tpr = cq;                    // threads per row
     const int rpi = 256 / tpr;             // rows per iteration
     const int q = threadIdx.x % tpr, rsub = threadIdx.x / tpr;
@@ -36,11 +40,11 @@ __global__ __launch_bounds__(256) void bn_colreduce_kernel(
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
     f32x4 mean = {0.f, 0.f, 0.f, 0.f}, rstd = {0.f, 0.f, 0.f, 0.f};
     if (MODE == 1) {
-        mean = *reinterpret_cast<const f32x4*>(stats + q * 4);
-        rstd = *reinterpret_cast<const f32x4*>(stats + C + q * 4);
+        mean = *reinterpret_cast<const f32x4*>(stats + c0 + q * 4);
+        rstd = *reinterpret_cast<const f32x4*>(stats + C + c0 + q * 4);
     }
     auto accum = [&](int r, f32x4& a1, f32x4& a2) {
-        const size_t o = (size_t)r * C + q * 4;
+        const size_t o = (size_t)r * C + c0 + q * 4;
         const f32x4 v = *reinterpret_cast<const f32x4*>(y + o);
         if (MODE == 0) {
             a1 += v;
@@ -81,15 +85,15 @@ __global__ __launch_bounds__(256) void bn_colreduce_kernel(
     }
     __syncthreads();
     // thread c (< C) sums the rpi row-subgroups for channel c in a fixed order
-    for (int c = threadIdx.x; c < C; c += 256) {
+    for (int c = threadIdx.x; c < Cg; c += 256) {
         float a1 = 0.f, a2 = 0.f;
         const int qq = c >> 2, e = c & 3;
         for (int rs = 0; rs < rpi; ++rs) {
             a1 += red[0][(rs * tpr + qq) * 4 + e];
             a2 += red[1][(rs * tpr + qq) * 4 + e];
         }
-        partial[(size_t)c * gridDim.x + blockIdx.x] = a1;
-        partial[(size_t)(C + c) * gridDim.x + blockIdx.x] = a2;
+        partial[(size_t)(c0 + c) * gridDim.x + blockIdx.x] = a1;
+        partial[(size_t)(C + c0 + c) * gridDim.x + blockIdx.x] = a2;
     }
 }
 
@@ -549,8 +553,9 @@ int grid_for(size_t total, int per_block = 256, int cap = 4096) {
 }
 
 struct ColPlan { int nblk; int rows_per_block; };
+int col_groups(int C) { return C > 1024 ? C / 1024 : 1; }
 ColPlan col_plan(int M, int C) {
-    const int rpi = 256 / (C >> 2);
+    const int rpi = 256 / ((C > 1024 ? 1024 : C) >> 2);
     // >= 8 iterations of the 4-way unrolled loop per block when M allows, <= kMaxPartBlocks blocks
     int rows = cdiv(M, kMaxPartBlocks);
     const int min_rows = 4 * rpi;          // at least one 4-way unrolled iteration per block
@@ -565,7 +570,8 @@ ColPlan col_plan(int M, int C) {
 size_t bn_partial_floats(int C) { return (size_t)kMaxPartBlocks * 2 * C; }
 
 static int check_c(int C) {
-    CILRS_CHECK(C % 4 == 0 && C >= 4 && C <= 1024 && 256 % (C / 4) == 0,
+    CILRS_CHECK(C % 4 == 0 && C >= 4 &&
+                    ((C <= 1024 && 256 % (C / 4) == 0) || (C <= 4096 && C % 1024 == 0)),
                 "batchnorm: unsupported channel count %d", C);
     return 0;
 }
@@ -578,7 +584,7 @@ int launch_bn_train_fwd(const float* y, int M, int C, const float* gamma, const 
     int nblk = pre_nblk;
     if (nblk <= 0) {
         const ColPlan p = col_plan(M, C);
-        bn_colreduce_kernel<0><<<p.nblk, 256, 0, s>>>(y, nullptr, nullptr, nullptr, partial, M, C,
+        bn_colreduce_kernel<0><<<dim3(p.nblk, col_groups(C)), 256, 0, s>>>(y, nullptr, nullptr, nullptr, partial, M, C,
                                                       0, p.rows_per_block);
         CILRS_LAUNCH_CHECK();
         nblk = p.nblk;
@@ -623,7 +629,7 @@ int launch_bn_bwd(const float* dz, const float* z, const float* y, int M, int C,
     int nblk = pre_nblk;
     if (nblk <= 0) {
         const ColPlan p = col_plan(M, C);
-        bn_colreduce_kernel<1><<<p.nblk, 256, 0, s>>>(y, dz, z, stats, partial, M, C, relu,
+        bn_colreduce_kernel<1><<<dim3(p.nblk, col_groups(C)), 256, 0, s>>>(y, dz, z, stats, partial, M, C, relu,
                                                       p.rows_per_block);
         CILRS_LAUNCH_CHECK();
         nblk = p.nblk;
@@ -654,6 +660,7 @@ int launch_bn_bwd_pool(const float* dpool, const unsigned char* argmax, const fl
                        int H, int W, int C, const float* gamma, const float* stats, float* dgamma,
                        float* dbeta, float* coef, float* partial, float* dy, hipStream_t s) {
     if (check_c(C)) return 1;
+    CILRS_CHECK(C <= 1024, "bn_bwd_pool: at most 1024 channels (got %d)", C);
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const int M = N * H * W;
     const ColPlan p = col_plan(M, C);

@@ -47,7 +47,8 @@ struct LinT { int in, out; size_t w, b; };
 // variant 1: BASELINE.json configs[3], "ResNet-50 backbone variant": Bottleneck [3,4,6,3] with the
 //            stride on the 3x3 convolution (torchvision's ResNet-50 v1.5), 2048-d features into the
 //            same heads.  The reference has no such model; parity is against the build's own CPU
-//            restatement (oracle/resnet50_oracle.py).  Inference only.
+//            restatement (oracle/resnet50_oracle.py).  Trains in fp32 through the same kernels;
+//            the 16-bit trunks are inference-only.
 struct Arch {
     int variant = 0;
     int feat = 512;                     // trunk feature width (avg-pool output)
@@ -536,9 +537,14 @@ int cilrs_variant_bn_info(int variant, int j, char* prefix, int prefix_cap, int*
 }
 
 int cilrs_segment_range(int seg, size_t* begin, size_t* end) {
-    CILRS_CHECK(seg >= 0 && seg < 6, "segment %d out of range", seg);
-    *begin = arch().seg_begin[seg];
-    *end = arch().seg_end[seg];
+    return cilrs_variant_segment_range(0, seg, begin, end);
+}
+
+int cilrs_variant_segment_range(int variant, int seg, size_t* begin, size_t* end) {
+    CILRS_CHECK(variant_ok(variant), "variant %d out of range", variant);
+    CILRS_CHECK(seg >= 0 && seg < 6 && begin && end, "segment %d out of range", seg);
+    *begin = arch(variant).seg_begin[seg];
+    *end = arch(variant).seg_end[seg];
     return 0;
 }
 
@@ -555,7 +561,7 @@ int cilrs_net_create_variant(int variant, int batch, int height, int width, cilr
     CILRS_CHECK(batch >= 1 && height >= 32 && width >= 32, "cilrs_net_create: bad geometry %d %d %d",
                 batch, height, width);
     const Arch& A = arch(variant);
-    const bool trainable = variant == 0;       // the ResNet-50 variant is inference-only
+    const bool trainable = true;
     cilrs_net* n = new cilrs_net();
     n->A = &A;
     n->B = batch; n->H = height; n->W = width;
@@ -629,8 +635,13 @@ int cilrs_net_create_variant(int variant, int batch, int height, int width, cilr
         const ConvT& c1 = A.convs[blk.conv1];
         const size_t act = (size_t)B * h * w * c1.cin;
         if (act > gmax) gmax = act;
-        if ((size_t)g1.M * c1.cout > gmax) gmax = (size_t)g1.M * c1.cout;
-        if ((size_t)g1.M * c1.cout > dymax) dymax = (size_t)g1.M * c1.cout;   // trunk dy tensors
+        // gradient buffers hold d(block input), d(block output) and every conv output's gradient
+        for (int ci : {blk.conv1, blk.conv2, blk.conv3, blk.down}) {
+            if (ci < 0) continue;
+            const size_t o = (size_t)n->cg[ci].M * A.convs[ci].cout;
+            if (o > gmax) gmax = o;
+            if (o > dymax) dymax = o;                                         // trunk dy tensors
+        }
         h = oh; w = ow;
     }
     n->featHW = h * w;
@@ -675,8 +686,15 @@ int cilrs_net_create_variant(int variant, int batch, int height, int width, cilr
         size_t need = bn_partial_floats(512);
         if (trainable)
             for (size_t ci = 0; ci < A.convs.size(); ++ci) {
+                // per-tile column partials: forward (conv output) and backward (the data
+                // gradient's output = this conv's input) reductions ride on the GEMM epilogues
                 const size_t t = (size_t)cdiv(n->cg[ci].M, 64) * 2 * A.convs[ci].cout;
                 if (t > need) need = t;
+                const size_t tb = (size_t)cdiv(B * n->cg[ci].H * n->cg[ci].W, 64) * 2 *
+                                  A.convs[ci].cin;
+                if (ci > 0 && tb > need) need = tb;
+                if (bn_partial_floats(A.convs[ci].cout) > need)
+                    need = bn_partial_floats(A.convs[ci].cout);
             }
         n->bn_partial = bump.take(need);
     }
@@ -754,7 +772,6 @@ static int forward_from_x4(cilrs_net* net, const cilrs_buffers* bufs, const floa
                            const int64_t* command, int train, float dropout_p, uint64_t seed,
                            float* controls, float* pred_speed, hipStream_t s, int half = 0) {
     const Arch& A = *net->A;
-    CILRS_CHECK(!train || A.variant == 0, "the ResNet-50 variant is inference-only");
     float* ws = reinterpret_cast<float*>(bufs->workspace);
     net->ws_base = ws;
     if (zero_counters_once(net, bufs->workspace, s)) return 1;
@@ -814,30 +831,37 @@ static int forward_from_x4(cilrs_net* net, const cilrs_buffers* bufs, const floa
         RUN(net, "maxpool", 0.0, 4.0 * net->cg[0].M * 64 * 1.25, s,
             launch_bn_relu_maxpool_fwd(ws + net->cg[0].y, ws + net->cg[0].stats, ws + net->pool,
                                        argmax, B, net->H0, net->W0, 64, s));
-        // ---- BasicBlocks ----
+        // ---- residual blocks: BasicBlock conv-BN-ReLU-conv-BN-(+id)-ReLU, Bottleneck with a third
+        //      conv-BN pair; the identity (or downsample branch) joins at the last BatchNorm ----
         cur = ws + net->pool;
         for (const BlockT& blk : A.blocks) {
-            const ConvT& c1 = A.convs[blk.conv1];
-            const ConvT& c2 = A.convs[blk.conv2];
-            const ConvG& g1 = net->cg[blk.conv1];
-            const ConvG& g2 = net->cg[blk.conv2];
-            nb = 0;
-            if (conv_fwd(net, c1, g1, cur, c1.cin, P + c1.w, ws + g1.y, ws, s, &nb)) return 1;
-            if (bn(blk.conv1, nullptr, 1, nb)) return 1;
+            const int chain[3] = {blk.conv1, blk.conv2, blk.conv3};
+            const int nchain = blk.conv3 >= 0 ? 3 : 2;
             const float* identity = cur;
-            if (blk.down >= 0) {
-                const ConvT& cd = A.convs[blk.down];
-                const ConvG& gd = net->cg[blk.down];
+            const float* x = cur;
+            for (int i = 0; i < nchain; ++i) {
+                const ConvT& c = A.convs[chain[i]];
+                const ConvG& g = net->cg[chain[i]];
                 nb = 0;
-                if (conv_fwd(net, cd, gd, cur, cd.cin, P + cd.w, ws + gd.y, ws, s, &nb)) return 1;
-                if (bn(blk.down, nullptr, 0, nb)) return 1;
-                identity = ws + gd.z;
+                if (conv_fwd(net, c, g, x, c.cin, P + c.w, ws + g.y, ws, s, &nb)) return 1;
+                if (i == 0 && blk.down >= 0) {
+                    // (issued after conv1 so that both convolutions reading `cur` are adjacent)
+                    if (bn(chain[0], nullptr, 1, nb)) return 1;
+                    const ConvT& cd = A.convs[blk.down];
+                    const ConvG& gd = net->cg[blk.down];
+                    nb = 0;
+                    if (conv_fwd(net, cd, gd, cur, cd.cin, P + cd.w, ws + gd.y, ws, s, &nb))
+                        return 1;
+                    if (bn(blk.down, nullptr, 0, nb)) return 1;
+                    identity = ws + gd.z;
+                } else if (i + 1 < nchain) {
+                    if (bn(chain[i], nullptr, 1, nb)) return 1;
+                } else {
+                    if (bn(chain[i], identity, 1, nb)) return 1;
+                }
+                x = ws + g.z;
             }
-            nb = 0;
-            if (conv_fwd(net, c2, g2, ws + g1.z, c2.cin, P + c2.w, ws + g2.y, ws, s, &nb))
-                return 1;
-            if (bn(blk.conv2, identity, 1, nb)) return 1;
-            cur = ws + g2.z;
+            cur = x;
         }
     } else {
         // eval: running statistics -> per-channel scale/shift (one launch for all 36 layers),
@@ -1231,16 +1255,16 @@ static int backward_heads(cilrs_net* net, const cilrs_buffers* bufs, const float
 int cilrs_net_backward(cilrs_net* net, const cilrs_buffers* bufs, const float* dcontrols,
                        const float* dpred_speed, int seg_begin, int seg_end, void* stream) {
     if (check_bufs(net, bufs, true)) return 1;
-    CILRS_CHECK(net->A->variant == 0, "the ResNet-50 variant is inference-only");
     CILRS_CHECK(net->trained_fwd, "backward needs a preceding train-mode forward on this plan");
     CILRS_CHECK(0 <= seg_begin && seg_begin <= seg_end && seg_end <= 6, "bad segment range");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const Arch& A = arch();
+    const Arch& A = *net->A;
     float* ws = reinterpret_cast<float*>(bufs->workspace);
     net->ws_base = ws;
     const float* P = bufs->params;
     float* Gp = bufs->grads;
     const int B = net->B;
+    auto last_conv = [&](const BlockT& blk) { return blk.conv3 >= 0 ? blk.conv3 : blk.conv2; };
 
     for (int seg = seg_begin; seg < seg_end; ++seg) {
         if (seg == 0) {
@@ -1249,8 +1273,8 @@ int cilrs_net_backward(cilrs_net* net, const cilrs_buffers* bufs, const float* d
             if (backward_heads(net, bufs, dcontrols, dpred_speed, nullptr, s)) return 1;
             // d visual -> avgpool backward -> grad of the last block's output, in G[3]
             RUN(net, "heads_bwd", 0.0, 0.0, s,
-                launch_avgpool_bwd(ws + net->dcombined, ws + net->G[3], B, net->featHW, 512, 640,
-                                   s));
+                launch_avgpool_bwd(ws + net->dcombined, ws + net->G[3], B, net->featHW, A.feat,
+                                   A.feat + 128, s));
             continue;
         }
         if (seg >= 1 && seg <= 4) {
@@ -1261,16 +1285,15 @@ int cilrs_net_backward(cilrs_net* net, const cilrs_buffers* bufs, const float* d
             for (int L = 1; L < layer; ++L) first += nblk[L - 1];
             for (int bi = first + nblk[layer - 1] - 1; bi >= first; --bi) {
                 const BlockT& blk = A.blocks[bi];
+                // conv-BN pairs of the main branch, in forward order (2: BasicBlock, 3: Bottleneck)
+                const int chain[3] = {blk.conv1, blk.conv2, blk.conv3};
+                const int nchain = blk.conv3 >= 0 ? 3 : 2;
                 const ConvT& c1 = A.convs[blk.conv1];
-                const ConvT& c2 = A.convs[blk.conv2];
                 const ConvG& g1 = net->cg[blk.conv1];
-                const ConvG& g2 = net->cg[blk.conv2];
-                const BnT& b1 = A.bns[c1.bn];
-                const BnT& b2 = A.bns[c2.bn];
                 // block input activation
                 const float* xin;
                 if (bi == 0) xin = ws + net->pool;
-                else xin = ws + net->cg[A.blocks[bi - 1].conv2].z;
+                else xin = ws + net->cg[last_conv(A.blocks[bi - 1])].z;
                 float* Gd = ws + net->G[3];
                 float* Gb = ws + net->G[1];
                 float* Gc = ws + net->G[2];
@@ -1283,38 +1306,54 @@ int cilrs_net_backward(cilrs_net* net, const cilrs_buffers* bufs, const float* d
                                    side_or(net, s, 0))) return 1;
                     return gbuf_side_end(net, gi);
                 };
-                // 1. out = relu(bn2(y2) + identity): masked grad -> Gb, dy2 -> Ga
-                int ga = kRingIdx[net->dy_pos];
-                net->dy_pos = (net->dy_pos + 1) % dy_ring_depth();
+                auto next_ring = [&]() {
+                    const int gi = kRingIdx[net->dy_pos];
+                    net->dy_pos = (net->dy_pos + 1) % dy_ring_depth();
+                    return gi;
+                };
+                // 1. out = relu(bn_last(y_last) + identity): masked grad -> Gb, dy_last -> Ga
+                int ga = next_ring();
                 if (gbuf_acquire(net, s, ga) || gbuf_acquire(net, s, 1)) return 1;
                 float* Ga = ws + net->G[ga];
-                RUN(net, "bn_bwd." + grp, 0.0, 4.0 * g2.M * c2.cout * 8.0, s,
-                    launch_bn_bwd(Gd, ws + g2.z, ws + g2.y, g2.M, c2.cout, P + b2.gamma,
-                                  ws + g2.stats, 1, Gp + b2.gamma, Gp + b2.beta, 0,
-                                  ws + net->bn_coef, ws + net->bn_partial, Ga, Gb,
-                                  net->bwd_nblk_next, s));
-                net->bwd_nblk_next = 0;
-                // 2./3. conv2: dW2 (side), da -> Gc
-                if (wgrad_side(c2, g2, ws + g1.z, ga, Gp + c2.w)) return 1;
-                if (gbuf_acquire(net, s, 2)) return 1;
-                int nb1 = 0;        // BN1's reductions ride on this dgrad's epilogue
-                if (conv_dgrad(net, c2, g2, Ga, P + c2.w, Gc, nullptr, ws, s, &g1, 1, &nb1))
-                    return 1;
-                // 4. a = relu(bn1(y1)): dy1 -> the other dy buffer
-                ga = kRingIdx[net->dy_pos];
-                net->dy_pos = (net->dy_pos + 1) % dy_ring_depth();
-                if (gbuf_acquire(net, s, ga)) return 1;
-                Ga = ws + net->G[ga];
-                RUN(net, "bn_bwd." + grp, 0.0, 4.0 * g1.M * c1.cout * 7.0, s,
-                    launch_bn_bwd(Gc, ws + g1.z, ws + g1.y, g1.M, c1.cout, P + b1.gamma,
-                                  ws + g1.stats, 1, Gp + b1.gamma, Gp + b1.beta, 0,
-                                  ws + net->bn_coef, ws + net->bn_partial, Ga, nullptr, nb1, s));
-                // 5. dW1 (side)
+                {
+                    const ConvT& cl = A.convs[chain[nchain - 1]];
+                    const ConvG& gl = net->cg[chain[nchain - 1]];
+                    const BnT& bl = A.bns[cl.bn];
+                    RUN(net, "bn_bwd." + grp, 0.0, 4.0 * gl.M * cl.cout * 8.0, s,
+                        launch_bn_bwd(Gd, ws + gl.z, ws + gl.y, gl.M, cl.cout, P + bl.gamma,
+                                      ws + gl.stats, 1, Gp + bl.gamma, Gp + bl.beta, 0,
+                                      ws + net->bn_coef, ws + net->bn_partial, Ga, Gb,
+                                      net->bwd_nblk_next, s));
+                    net->bwd_nblk_next = 0;
+                }
+                // 2. walk the main branch backwards: dW_i (side), d(input of conv_i) -> Gc, then
+                //    a = relu(bn_{i-1}(y_{i-1})): dy_{i-1} -> the next dy buffer
+                for (int i = nchain - 1; i >= 1; --i) {
+                    const ConvT& c = A.convs[chain[i]];
+                    const ConvG& g = net->cg[chain[i]];
+                    const ConvT& cp = A.convs[chain[i - 1]];
+                    const ConvG& gp = net->cg[chain[i - 1]];
+                    const BnT& bp = A.bns[cp.bn];
+                    if (wgrad_side(c, g, ws + gp.z, ga, Gp + c.w)) return 1;
+                    if (gbuf_acquire(net, s, 2)) return 1;
+                    int nbp = 0;    // the previous BatchNorm's reductions ride on this dgrad's epilogue
+                    if (conv_dgrad(net, c, g, Ga, P + c.w, Gc, nullptr, ws, s, &gp, 1, &nbp))
+                        return 1;
+                    ga = next_ring();
+                    if (gbuf_acquire(net, s, ga)) return 1;
+                    Ga = ws + net->G[ga];
+                    RUN(net, "bn_bwd." + grp, 0.0, 4.0 * gp.M * cp.cout * 7.0, s,
+                        launch_bn_bwd(Gc, ws + gp.z, ws + gp.y, gp.M, cp.cout, P + bp.gamma,
+                                      ws + gp.stats, 1, Gp + bp.gamma, Gp + bp.beta, 0,
+                                      ws + net->bn_coef, ws + net->bn_partial, Ga, nullptr, nbp,
+                                      s));
+                }
+                // 3. dW1 (side)
                 if (wgrad_side(c1, g1, xin, ga, Gp + c1.w)) return 1;
                 if (blk.down < 0) {
-                    // 6. dx = dgrad(conv1) + identity grad (Gb) -> Gd
-                    // ... and carries the reductions of the previous block's bn2
-                    const ConvG* prev = bi > 0 ? &net->cg[A.blocks[bi - 1].conv2] : nullptr;
+                    // 4. dx = dgrad(conv1) + identity grad (Gb) -> Gd
+                    // ... and carries the reductions of the previous block's last BatchNorm
+                    const ConvG* prev = bi > 0 ? &net->cg[last_conv(A.blocks[bi - 1])] : nullptr;
                     if (conv_dgrad(net, c1, g1, Ga, P + c1.w, Gd, Gb, ws, s, prev, 1,
                                    &net->bwd_nblk_next)) return 1;
                 } else {
@@ -1322,9 +1361,8 @@ int cilrs_net_backward(cilrs_net* net, const cilrs_buffers* bufs, const float* d
                     const ConvG& gd = net->cg[blk.down];
                     const BnT& bd = A.bns[cd.bn];
                     if (conv_dgrad(net, c1, g1, Ga, P + c1.w, Gd, nullptr, ws, s)) return 1;
-                    // 7. identity = bn_d(conv_d(x)) (no ReLU): dy_d -> Gc
-                    const int gdn = kRingIdx[net->dy_pos];
-                    net->dy_pos = (net->dy_pos + 1) % dy_ring_depth();
+                    // 5. identity = bn_d(conv_d(x)) (no ReLU): dy_d -> a dy buffer
+                    const int gdn = next_ring();
                     if (gbuf_acquire(net, s, gdn)) return 1;
                     float* Gdn = ws + net->G[gdn];
                     RUN(net, "bn_bwd." + grp, 0.0, 4.0 * gd.M * cd.cout * 6.0, s,
@@ -1332,7 +1370,7 @@ int cilrs_net_backward(cilrs_net* net, const cilrs_buffers* bufs, const float* d
                                       ws + gd.stats, 0, Gp + bd.gamma, Gp + bd.beta, 0,
                                       ws + net->bn_coef, ws + net->bn_partial, Gdn, nullptr, 0, s));
                     if (wgrad_side(cd, gd, xin, gdn, Gp + cd.w)) return 1;
-                    // 8. dx += dgrad(conv_d)
+                    // 6. dx += dgrad(conv_d)
                     if (conv_dgrad(net, cd, gd, Gdn, P + cd.w, Gd, Gd, ws, s)) return 1;
                 }
             }
@@ -1361,7 +1399,8 @@ int cilrs_net_backward(cilrs_net* net, const cilrs_buffers* bufs, const float* d
 
 static int backward_heads(cilrs_net* net, const cilrs_buffers* bufs, const float* dcontrols,
                           const float* dps, const int64_t*, hipStream_t s) {
-    const Arch& A = arch();
+    const Arch& A = *net->A;
+    const int feat = A.feat, comb = A.feat + 128;
     float* ws = reinterpret_cast<float*>(bufs->workspace);
     const float* P = bufs->params;
     float* Gp = bufs->grads;
@@ -1418,26 +1457,27 @@ static int backward_heads(cilrs_net* net, const cilrs_buffers* bufs, const float
            dscale);
     dg(h.g[4], ws + net->dp2, 256, A.sp3, ws + net->dp1, 256, ws + net->p1, 256, dscale);
     if (run(1, h, 5)) return 1;
-    // ---- first layers (640 -> 256 per branch; 512 -> 256 speed predictor, visual half only) ----
+    // ---- first layers (feat+128 -> 256 per branch; feat -> 256 speed predictor, visual half
+    //      only; 640 / 512 for the reference's ResNet-34 trunk) ----
     for (int k = 0; k < 4; ++k)
-        wg(h.g[k], ws + net->dh1[k], 256, ws + net->combined, 640, A.br[k][0]);
-    wg(h.g[4], ws + net->dp1, 256, ws + net->combined, 640, A.sp0);
+        wg(h.g[k], ws + net->dh1[k], 256, ws + net->combined, comb, A.br[k][0]);
+    wg(h.g[4], ws + net->dp1, 256, ws + net->combined, comb, A.sp0);
     if (run(2, h, 5)) return 1;
     for (int k = 0; k < 4; ++k)
-        dg(h.g[k], ws + net->dh1[k], 256, A.br[k][0], ws + net->dcomb_part[k], 640, nullptr, 0, 1.f);
-    dg(h.g[4], ws + net->dp1, 256, A.sp0, ws + net->dcomb_part[4], 640, nullptr, 0, 1.f);
+        dg(h.g[k], ws + net->dh1[k], 256, A.br[k][0], ws + net->dcomb_part[k], comb, nullptr, 0, 1.f);
+    dg(h.g[4], ws + net->dp1, 256, A.sp0, ws + net->dcomb_part[4], comb, nullptr, 0, 1.f);
     if (run(1, h, 5)) return 1;
-    // d combined = sum of the four branch contributions (640 wide) + speed predictor (512 wide)
+    // d combined = sum of the four branch contributions (comb wide) + speed predictor (feat wide)
     RUN(net, "heads_bwd", 0.0, 0.0, s,
         launch_sum_parts(ws + net->dcomb_part[0], ws + net->dcomb_part[1],
                          ws + net->dcomb_part[2], ws + net->dcomb_part[3],
-                         ws + net->dcomb_part[4], dcomb, B, 640, 512, s));
+                         ws + net->dcomb_part[4], dcomb, B, comb, feat, s));
     // ---- speed encoder (the speed half of `combined`) ----
     RUN(net, "heads_bwd", 0.0, 0.0, s,
-        launch_relu_mask(dcomb + 512, ws + net->combined + 512, B, 128, 640, 640, 1.0f, s));
-    wg(h.g[0], dcomb + 512, 640, ws + net->s1, 128, A.se3);
+        launch_relu_mask(dcomb + feat, ws + net->combined + feat, B, 128, comb, comb, 1.0f, s));
+    wg(h.g[0], dcomb + feat, comb, ws + net->s1, 128, A.se3);
     if (run(2, h, 1)) return 1;
-    dg(h.g[0], dcomb + 512, 640, A.se3, ws + net->ds1, 128, ws + net->s1, 128, dscale);
+    dg(h.g[0], dcomb + feat, comb, A.se3, ws + net->ds1, 128, ws + net->s1, 128, dscale);
     if (run(1, h, 1)) return 1;
     wg(h.g[0], ws + net->ds1, 128, ws + net->speed_in, 1, A.se0);
     if (run(2, h, 1)) return 1;

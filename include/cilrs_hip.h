@@ -56,8 +56,8 @@ size_t cilrs_bn_arena_floats(void);
  *            stacks [3,4,6,3] (stride on the 3x3 convolution), 2048-d features into the same
  *            speed encoder / four branches / speed predictor (first Linear layers 2176 and 2048
  *            wide).  The reference has no such model: parity is against the build's own CPU
- *            restatement.  Inference only (fp32, fp16 or bf16 trunk); train-mode forward and
- *            backward return an error. */
+ *            restatement (oracle/resnet50_oracle.py).  Trains in fp32 (train-mode forward,
+ *            backward, the same segments); the fp16 / bf16 trunks are inference-only. */
 int cilrs_num_variants(void);
 int cilrs_variant_num_params(int variant);
 int cilrs_variant_num_bn(int variant);
@@ -189,6 +189,8 @@ int cilrs_net_backward(cilrs_net* net, const cilrs_buffers* bufs, const float* d
                        const float* dpred_speed, int seg_begin, int seg_end, void* stream);
 /* float range [begin,end) of the gradient arena that segment `seg` produces */
 int cilrs_segment_range(int seg, size_t* begin, size_t* end);
+/* the same for architecture variant `variant` (0 = the reference's ResNet-34, 1 = ResNet-50) */
+int cilrs_variant_segment_range(int variant, int seg, size_t* begin, size_t* end);
 
 /* torch.nn.utils.clip_grad_norm_ (notebook/notebook.ipynb:553-554): out[0] = total L2 norm,
  * out[1] = min(1, max_norm/(norm+1e-6)) (1 when max_norm <= 0); device results, no sync.

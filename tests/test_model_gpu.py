@@ -113,9 +113,9 @@ def _grad_views(eng):
     return {n: g for (n, _, _, _), g in zip(eng.params_layout, eng.grad_views)}
 
 
-def _fp64_grads(ocfg, imgs, spds, cmds, tgts):
+def _fp64_grads(ocfg, imgs, spds, cmds, tgts, build=None):
     """Gradients of the same step in float64 (ground truth for the error budget)."""
-    m64 = O.build_oracle(0).double().train()
+    m64 = (build or O.build_oracle)(0).double().train()
     pc, ps = m64(imgs.double(), spds.double(), cmds)
     loss, _ = O.compute_loss(ocfg, pc, tgts.double(), ps, spds.double())
     loss.backward()
@@ -989,8 +989,66 @@ def test_resnet50_variant_fp32_and_bf16_forward_vs_its_oracle():
     for _ in range(2):
         got = pr.predict_batch(u8, kmh, cmd.numpy())
     assert np.abs(got[:, :3] - cb.cpu().numpy()).max() <= 1e-6
-    with pytest.raises(RuntimeError):
-        m.train()(img.cuda(), spd.cuda(), cmd.cuda())                    # inference-only variant
+
+
+@pytest.mark.parametrize("B,H,W,cfg_name", [(6, 88, 200, "A"), (4, 176, 400, "B")])
+def test_resnet50_variant_train_step_vs_its_oracle(B, H, W, cfg_name):
+    """The variant TRAINS through the same fp32 kernels (Bottleneck chains: three conv-BN pairs,
+    1x1 convolutions up to 2,048 channels, the stride on the 3x3).  One fused step against
+    oracle/resnet50_oracle.py: train-mode outputs, the six loss terms, every BatchNorm layer's
+    running statistics, per-tensor gradients budgeted against a float64 run, the clip norm, the
+    parameters after Adam; then a second step (loss within 1e-3) so the carried state is used."""
+    import resnet50_oracle as R
+    from cilrs_mi355 import CILRSResNet50, Trainer
+    cfg, ocfg = _cfgs()[cfg_name]
+    imgs, spds, cmds, tgts = O.synthetic_batch(B, seed=77, h=H, w=W)[:4]
+    m = CILRSResNet50(4, 0.0)
+    m.load_state_dict(O.portable_state_dict(m.state_dict(), 0), strict=True)
+    m = m.cuda()
+    tr = Trainer(m, cfg)
+    eng = tr.eng
+    m.train()
+    controls, pred_speed, pl = eng.run_forward(*to_dev(imgs, spds, cmds), True, 0.0, 0)
+    _, dc, dp = tr.loss(controls, tgts.cuda(), pred_speed, spds.cuda())
+    eng.run_backward(pl, dc, dp)
+    tr.optimizer_step(1.0)
+    got = tr.losses()
+    orc = R.build_oracle50(0)
+    oopt = O.make_optimizer(orc, ocfg)
+    with torch.no_grad():
+        oc, osp = R.build_oracle50(0).train()(imgs, spds, cmds)
+    assert (controls.cpu() - oc).abs().max() <= TOL_OUT, float((controls.cpu() - oc).abs().max())
+    assert (pred_speed.cpu() - osp).abs().max() <= TOL_OUT
+    g64 = _fp64_grads(ocfg, imgs, spds, cmds, tgts, build=R.build_oracle50)
+    old, ognorm = O.train_step(orc, oopt, ocfg, imgs, spds, cmds, tgts)
+    for k, v in old.items():
+        assert abs(got[k] - v) <= 1e-4 * max(1.0, abs(v)), (k, got[k], v)
+    coef = 1.0
+    if cfg.grad_clip > 0:
+        gn = tr.grad_norm()
+        n64 = float(torch.sqrt(sum((g.double() ** 2).sum() for g in g64.values())))
+        assert abs(gn - n64) <= 5e-4 * n64, (gn, n64, ognorm)
+        coef = min(1.0, cfg.grad_clip / (n64 + 1e-6))
+    _grad_budget_check(f"ResNet-50 B={B} {H}x{W} cfg {cfg_name}", list(orc.named_parameters()),
+                       _grad_views(eng), g64, coef, cos_floor=2.5e-5)
+    sd, osd = m.state_dict(), orc.state_dict()
+    nbn = 0
+    for k, v in osd.items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert (sd[k].cpu() - v).abs().max() <= 1e-5 * max(1.0, float(v.abs().max())), k
+        elif k.endswith("num_batches_tracked"):
+            assert int(sd[k]) == int(v) == 1
+            nbn += 1
+    assert nbn == 53
+    pv = dict(m.named_parameters())
+    for n, p in orc.named_parameters():
+        _close_params(pv[n].detach().cpu(), p.detach(), cfg.lr, 1)
+    # second step through the fused entry point, from the (slightly different) carried state
+    imgs2, spds2, cmds2, tgts2 = O.synthetic_batch(B, seed=78, h=H, w=W)[:4]
+    tr.train_step(*to_dev(imgs2, spds2, cmds2, tgts2))
+    got2 = tr.losses()
+    old2, _ = O.train_step(orc, oopt, ocfg, imgs2, spds2, cmds2, tgts2)
+    assert abs(got2["total"] - old2["total"]) <= 1e-3 * max(1.0, abs(old2["total"]))
 
 
 def test_bf16_trunk_on_the_reference_network():
