@@ -523,7 +523,48 @@ def main():
                          "avg_launch_us": round(cms / max(ncalls, 1) * 1e3, 2),
                          "gflop_per_frame_trunk": round(cfl / b50 / 1e9, 3)},
             "device_ms_by_layer": {k: round(v["ms"] / 3, 4) for k, v in sorted(t50.items())}}
-        del m50, eng50, pl50, u50
+        del pl50, u50
+        # ... and the same variant TRAINING in fp32 (Bottleneck chains through the fp32 kernels
+        # of the headline path; no bf16 training kernels exist): Config A step at 176x400
+        from cilrs_mi355 import CONFIG_A as _CA
+        b50t = int(os.environ.get("CILRS_BENCH_R50_TRAIN_B", "64"))
+        tr50 = Trainer(m50, _CA)
+        g50 = torch.Generator(device="cpu").manual_seed(5)
+        batch50 = (torch.randn(b50t, 3, 176, 400, generator=g50).to(dev),
+                   torch.rand(b50t, generator=g50).to(dev),
+                   torch.randint(0, 4, (b50t,), generator=g50).to(dev),
+                   torch.rand(b50t, 3, generator=g50).to(dev))
+        for _ in range(2):
+            tr50.train_step(*batch50)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(5):
+            tr50.train_step(*batch50)
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t1) / 5
+        l50 = tr50.losses()
+        plt = eng50.plan(b50t, 176, 400)
+        plt.profile_reset()
+        plt.profile(True)
+        for _ in range(2):
+            tr50.train_step(*batch50)
+        torch.cuda.synchronize(dev)
+        tt = plt.profile_table()
+        plt.profile(False)
+        conv = [v for k, v in tt.items() if k.startswith("conv_")]
+        cms = sum(v["ms"] for v in conv) / 2
+        cfl = sum(v["flops"] for v in conv) / 2
+        out["resnet50_train_f32"] = {
+            "workload": f"CILRS ResNet-50 variant train step (fwd+loss+bwd+Adam), Config A, "
+                        f"176x400 RGB, B={b50t}, fp32, random-init weights, synthetic batch",
+            "frames_per_s": round(b50t / dt, 1), "ms_per_step": round(dt * 1e3, 3),
+            "dtype": "f32", "n_gpus": 1, "final_loss": round(l50["total"], 6),
+            "conv_tflops": round(cfl / max(cms, 1e-9) / 1e9, 1),
+            "conv_frac_of_f32_matrix_peak": round(cfl / max(cms, 1e-9) / 1e9 / PEAK_F32_MATRIX_TFLOPS, 4),
+            "gflop_per_frame": round(cfl / b50t / 1e9, 2),
+            "device_ms_by_kernel": {k: round(v["ms"] / 2, 3) for k, v in
+                                    sorted(tt.items(), key=lambda kv: -kv[1]["ms"])[:12]}}
+        del m50, eng50, tr50, plt, batch50
         torch.cuda.empty_cache()
 
     if want_parity:

@@ -97,42 +97,51 @@ __global__ __launch_bounds__(256) void bn_colreduce_kernel(
     }
 }
 
-// Sum one channel's per-block partials (channel-major layout [2][C][nblk]): one wave per channel,
-// lanes stride the blocks in double over four independent streams, fixed-order shuffle tree
-// (deterministic).  Returns the two sums to lane 0 of the wave.
-constexpr int kFinChannels = 4;       // channels (waves) per finalize block
+// Sum one channel's per-block partials (channel-major layout [2][C][nblk]): one 256-thread block
+// per channel.  The kernel is pure load latency (the partials were written by another kernel's
+// blocks on other XCDs, so they come from the memory side): every thread issues all of its loads
+// (8 per array cover 2,048 partials) before the first add, then a fixed-order double tree --
+// shuffles inside a wave, LDS across the four waves (deterministic).  Returns the two sums to
+// thread 0.  (One wave per channel with a 4-way unrolled loop took 5.5 us per launch at
+// nblk = 2,200: nine dependent memory round trips.)
+constexpr int kFinThreads = 256;
 __device__ __forceinline__ bool partial_sums(const float* __restrict__ partial, const int nblk,
                                              const int C, int& c, double& s1, double& s2) {
-    const int lane = threadIdx.x & 63;
-    c = blockIdx.x * kFinChannels + (threadIdx.x >> 6);
-    if (c >= C) return false;
+    __shared__ double red[2][kFinThreads / 64];
+    c = blockIdx.x;
     const float* r1 = partial + (size_t)c * nblk;
     const float* r2 = partial + (size_t)(C + c) * nblk;
-    double p1[4] = {0.0, 0.0, 0.0, 0.0}, p2[4] = {0.0, 0.0, 0.0, 0.0};
-    int b = lane;
-    for (; b + 192 < nblk; b += 256) {
+    double p1 = 0.0, p2 = 0.0;
+    for (int base = 0; base < nblk; base += 8 * kFinThreads) {
+        float v1[8], v2[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            p1[u] += (double)r1[b + 64 * u];
-            p2[u] += (double)r2[b + 64 * u];
+        for (int u = 0; u < 8; ++u) {
+            const int b = base + threadIdx.x + kFinThreads * u;
+            v1[u] = b < nblk ? r1[b] : 0.f;
+            v2[u] = b < nblk ? r2[b] : 0.f;
         }
+        p1 += (((double)v1[0] + (double)v1[1]) + ((double)v1[2] + (double)v1[3])) +
+              (((double)v1[4] + (double)v1[5]) + ((double)v1[6] + (double)v1[7]));
+        p2 += (((double)v2[0] + (double)v2[1]) + ((double)v2[2] + (double)v2[3])) +
+              (((double)v2[4] + (double)v2[5]) + ((double)v2[6] + (double)v2[7]));
     }
-    for (; b < nblk; b += 64) {
-        p1[0] += (double)r1[b];
-        p2[0] += (double)r2[b];
-    }
-    s1 = (p1[0] + p1[1]) + (p1[2] + p1[3]);
-    s2 = (p2[0] + p2[1]) + (p2[2] + p2[3]);
 #pragma unroll
     for (int sft = 32; sft > 0; sft >>= 1) {
-        s1 += __shfl_xor(s1, sft);
-        s2 += __shfl_xor(s2, sft);
+        p1 += __shfl_xor(p1, sft);
+        p2 += __shfl_xor(p2, sft);
     }
-    return lane == 0;
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = p1;
+        red[1][threadIdx.x >> 6] = p2;
+    }
+    __syncthreads();
+    s1 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    s2 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    return threadIdx.x == 0;
 }
 
 // stats layout (floats): [0,C) mean | [C,2C) rstd | [2C,3C) w = gamma*rstd | [3C,4C) b = beta-mean*w
-__global__ __launch_bounds__(64 * kFinChannels) void bn_fwd_finalize_kernel(
+__global__ __launch_bounds__(kFinThreads) void bn_fwd_finalize_kernel(
     const float* __restrict__ partial, const int nblk, const int M, const int C,
     const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
     float* running_var, long long* nbt, const float momentum, const float eps,
@@ -220,7 +229,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 }
 
 // coef layout: [0,C) c1 = gamma*rstd | [C,2C) c2 = sum(g)/M | [2C,3C) c3 = sum(g*xhat)/M
-__global__ __launch_bounds__(64 * kFinChannels) void bn_bwd_finalize_kernel(
+__global__ __launch_bounds__(kFinThreads) void bn_bwd_finalize_kernel(
     const float* __restrict__ partial, const int nblk, const int M, const int C,
     const float* __restrict__ gamma, const float* __restrict__ stats, float* dgamma,
     float* dbeta, float* __restrict__ coef, const int accumulate) {
@@ -409,62 +418,97 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(
     }
 }
 
-// g(n,h,w,c) = [y*w+b > 0] * sum over the pooling windows that selected (h,w) of dpool
-__device__ __forceinline__ f32x4 pool_relu_grad(const float* __restrict__ dpool,
-                                                const unsigned char* __restrict__ argmax,
-                                                const f32x4 yv, const f32x4 sw, const f32x4 sb,
-                                                const int n, const int h, const int w, const int q,
-                                                const int cq, const int Ho, const int Wo) {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int kh = 0; kh < 3; ++kh) {
-        const int t = h + 1 - kh;
-        if (t < 0 || (t & 1)) continue;
-        const int oh = t >> 1;
-        if (oh >= Ho) continue;
-        for (int kw = 0; kw < 3; ++kw) {
-            const int u = w + 1 - kw;
-            if (u < 0 || (u & 1)) continue;
-            const int ow = u >> 1;
-            if (ow >= Wo) continue;
-            const size_t o = (((size_t)(n * Ho + oh) * Wo + ow) * cq + q) * 4;
-            const uchar4 a = *reinterpret_cast<const uchar4*>(argmax + o);
-            const f32x4 g = *reinterpret_cast<const f32x4*>(dpool + o);
-            const int k = kh * 3 + kw;
-            if (a.x == k) acc[0] += g[0];
-            if (a.y == k) acc[1] += g[1];
-            if (a.z == k) acc[2] += g[2];
-            if (a.w == k) acc[3] += g[3];
-        }
-    }
-    const f32x4 z = yv * sw + sb;
+// g(n,h,w,c) = [y*w+b > 0] * sum over the pooling windows that selected (h,w) of dpool:
+// pixel (h,w) is reached by window (oh,ow) through tap (kh,kw) when h + 1 - kh = 2*oh and
+// w + 1 - kw = 2*ow; torch accumulates the windows in (kh, kw) ascending order.
+// Computed for a 2x2 input patch (2a..2a+1, 2b..2b+1) at once.  A pixel's candidate windows
+// depend on the parity of its coordinates (1, 2, 2 or 4 of them), so a per-pixel gather
+// diverges inside a wave and issues its loads one dependent window at a time (measured: 131 us
+// for the reduction pass at B=128, 1.45 TB/s); a patch
+// always needs exactly the four windows (a,b) (a,b+1) (a+1,b) (a+1,b+1): every thread issues the
+// same 12 independent loads (4 pixels of y, 4 windows of argmax + dpool).  Accumulation order per
+// pixel is (kh ascending, kw ascending).
+struct PoolPatch {
+    f32x4 y[4];        // pixels (2a,2b) (2a,2b+1) (2a+1,2b) (2a+1,2b+1); zeros where outside
+    f32x4 g[4];
+};
+__device__ __forceinline__ f32x4 pool_sel(const uchar4 a, const int k, const f32x4 d) {
+    f32x4 r;
+    r[0] = a.x == k ? d[0] : 0.f;
+    r[1] = a.y == k ? d[1] : 0.f;
+    r[2] = a.z == k ? d[2] : 0.f;
+    r[3] = a.w == k ? d[3] : 0.f;
+    return r;
+}
+__device__ __forceinline__ void pool_patch(const float* __restrict__ y,
+                                           const float* __restrict__ dpool,
+                                           const unsigned char* __restrict__ argmax,
+                                           const f32x4 sw, const f32x4 sb, const int n,
+                                           const int a, const int b, const int q, const int H,
+                                           const int W, const int C, const int Ho, const int Wo,
+                                           PoolPatch& pp) {
+    const int cq = C >> 2;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const bool ph1 = 2 * a + 1 < H, pw1 = 2 * b + 1 < W;       // second row / column of the patch
+    const bool wh1 = a + 1 < Ho, ww1 = b + 1 < Wo;             // second window row / column
+    const size_t p00 = (((size_t)n * H + 2 * a) * W + 2 * b) * C + q * 4;
+    pp.y[0] = *reinterpret_cast<const f32x4*>(y + p00);
+    pp.y[1] = pw1 ? *reinterpret_cast<const f32x4*>(y + p00 + C) : zero;
+    pp.y[2] = ph1 ? *reinterpret_cast<const f32x4*>(y + p00 + (size_t)W * C) : zero;
+    pp.y[3] = ph1 && pw1 ? *reinterpret_cast<const f32x4*>(y + p00 + (size_t)W * C + C) : zero;
+    const size_t w00 = (((size_t)(n * Ho + a) * Wo + b) * cq + q) * 4;
+    const size_t dw = (size_t)cq * 4, dh = (size_t)Wo * cq * 4;
+    const uchar4 none = {255, 255, 255, 255};
+    const uchar4 a00 = *reinterpret_cast<const uchar4*>(argmax + w00);
+    const uchar4 a01 = ww1 ? *reinterpret_cast<const uchar4*>(argmax + w00 + dw) : none;
+    const uchar4 a10 = wh1 ? *reinterpret_cast<const uchar4*>(argmax + w00 + dh) : none;
+    const uchar4 a11 = wh1 && ww1 ? *reinterpret_cast<const uchar4*>(argmax + w00 + dh + dw) : none;
+    const f32x4 d00 = *reinterpret_cast<const f32x4*>(dpool + w00);
+    const f32x4 d01 = ww1 ? *reinterpret_cast<const f32x4*>(dpool + w00 + dw) : zero;
+    const f32x4 d10 = wh1 ? *reinterpret_cast<const f32x4*>(dpool + w00 + dh) : zero;
+    const f32x4 d11 = wh1 && ww1 ? *reinterpret_cast<const f32x4*>(dpool + w00 + dh + dw) : zero;
+    // tap index k = kh*3 + kw of the window that reaches the pixel
+    pp.g[0] = pool_sel(a00, 4, d00);
+    pp.g[1] = pool_sel(a01, 3, d01) + pool_sel(a00, 5, d00);
+    pp.g[2] = pool_sel(a10, 1, d10) + pool_sel(a00, 7, d00);
+    pp.g[3] = ((pool_sel(a11, 0, d11) + pool_sel(a10, 2, d10)) + pool_sel(a01, 6, d01)) +
+              pool_sel(a00, 8, d00);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) acc[e] = z[e] > 0.f ? acc[e] : 0.f;
-    return acc;
+    for (int i = 0; i < 4; ++i) {
+        const f32x4 z = pp.y[i] * sw + sb;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pp.g[i][e] = z[e] > 0.f ? pp.g[i][e] : 0.f;
+    }
+    if (!pw1) { pp.g[1] = zero; pp.g[3] = zero; }
+    if (!ph1) { pp.g[2] = zero; pp.g[3] = zero; }
 }
 
-// column partials of the stem's BatchNorm backward (layout of bn_colreduce_kernel<1>)
+// column partials of the stem's BatchNorm backward (layout of bn_colreduce_kernel<1>); a block
+// owns `patches_per_block` consecutive 2x2 patches
 __global__ __launch_bounds__(256) void bn_colreduce_pool_kernel(
     const float* __restrict__ y, const float* __restrict__ dpool,
     const unsigned char* __restrict__ argmax, const float* __restrict__ stats,
     float* __restrict__ partial, const int N, const int H, const int W, const int C, const int Ho,
-    const int Wo, const int rows_per_block) {
+    const int Wo, const int patches_per_block) {
     __shared__ float red[2][256 * 4];
-    const int M = N * H * W;
-    const int cq = C >> 2, tpr = cq, rpi = 256 / tpr;
-    const int q = threadIdx.x % tpr, rsub = threadIdx.x / tpr;
-    const int row_begin = blockIdx.x * rows_per_block;
-    const int row_end = min(M, row_begin + rows_per_block);
+    const int PH = (H + 1) >> 1, PW = (W + 1) >> 1;
+    const int NP = N * PH * PW;
+    const int cq = C >> 2, tpr = cq, ppi = 256 / tpr;
+    const int q = threadIdx.x % tpr, psub = threadIdx.x / tpr;
+    const int p_begin = blockIdx.x * patches_per_block;
+    const int p_end = min(NP, p_begin + patches_per_block);
     const f32x4 mean = *reinterpret_cast<const f32x4*>(stats + q * 4);
     const f32x4 rstd = *reinterpret_cast<const f32x4*>(stats + C + q * 4);
     const f32x4 sw = *reinterpret_cast<const f32x4*>(stats + 2 * C + q * 4);
     const f32x4 sb = *reinterpret_cast<const f32x4*>(stats + 3 * C + q * 4);
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
-    for (int r = row_begin + rsub; r < row_end; r += rpi) {
-        const int w = r % W, t = r / W, h = t % H, n = t / H;
-        const f32x4 yv = *reinterpret_cast<const f32x4*>(y + (size_t)r * C + q * 4);
-        const f32x4 g = pool_relu_grad(dpool, argmax, yv, sw, sb, n, h, w, q, cq, Ho, Wo);
-        s1 += g;
-        s2 += g * ((yv - mean) * rstd);
+    for (int p = p_begin + psub; p < p_end; p += ppi) {
+        const int b = p % PW, t = p / PW, a = t % PH, n = t / PH;
+        PoolPatch pp;
+        pool_patch(y, dpool, argmax, sw, sb, n, a, b, q, H, W, C, Ho, Wo, pp);
+        s1 += (pp.g[0] + pp.g[1]) + (pp.g[2] + pp.g[3]);
+        s2 += (pp.g[0] * ((pp.y[0] - mean) * rstd) + pp.g[1] * ((pp.y[1] - mean) * rstd)) +
+              (pp.g[2] * ((pp.y[2] - mean) * rstd) + pp.g[3] * ((pp.y[3] - mean) * rstd));
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -475,7 +519,7 @@ __global__ __launch_bounds__(256) void bn_colreduce_pool_kernel(
     for (int c = threadIdx.x; c < C; c += 256) {
         float a1 = 0.f, a2 = 0.f;
         const int qq = c >> 2, e = c & 3;
-        for (int rs = 0; rs < rpi; ++rs) {
+        for (int rs = 0; rs < ppi; ++rs) {
             a1 += red[0][(rs * tpr + qq) * 4 + e];
             a2 += red[1][(rs * tpr + qq) * 4 + e];
         }
@@ -490,14 +534,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pool_kernel(
     const float* __restrict__ coef, float* __restrict__ dy, const int N, const int H, const int W,
     const int C, const int Ho, const int Wo) {
     const int cq = C >> 2;
-    const size_t total4 = (size_t)N * H * W * cq;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
+    const int PH = (H + 1) >> 1, PW = (W + 1) >> 1;
+    const size_t total = (size_t)N * PH * PW * cq;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (size_t)gridDim.x * blockDim.x) {
         const int q = (int)(i % cq);
         size_t p = i / cq;
-        const int w = (int)(p % W); p /= W;
-        const int h = (int)(p % H);
-        const int n = (int)(p / H);
+        const int b = (int)(p % PW); p /= PW;
+        const int a = (int)(p % PH);
+        const int n = (int)(p / PH);
         const f32x4 mean = *reinterpret_cast<const f32x4*>(stats + q * 4);
         const f32x4 rstd = *reinterpret_cast<const f32x4*>(stats + C + q * 4);
         const f32x4 sw = *reinterpret_cast<const f32x4*>(stats + 2 * C + q * 4);
@@ -505,10 +550,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pool_kernel(
         const f32x4 c1 = *reinterpret_cast<const f32x4*>(coef + q * 4);
         const f32x4 c2 = *reinterpret_cast<const f32x4*>(coef + C + q * 4);
         const f32x4 c3 = *reinterpret_cast<const f32x4*>(coef + 2 * C + q * 4);
-        const f32x4 yv = *reinterpret_cast<const f32x4*>(y + i * 4);
-        const f32x4 g = pool_relu_grad(dpool, argmax, yv, sw, sb, n, h, w, q, cq, Ho, Wo);
-        const f32x4 xh = (yv - mean) * rstd;
-        *reinterpret_cast<f32x4*>(dy + i * 4) = (g - c2 - xh * c3) * c1;
+        PoolPatch pp;
+        pool_patch(y, dpool, argmax, sw, sb, n, a, b, q, H, W, C, Ho, Wo, pp);
+        const bool ph1 = 2 * a + 1 < H, pw1 = 2 * b + 1 < W;
+        const size_t p00 = (((size_t)n * H + 2 * a) * W + 2 * b) * C + q * 4;
+        const size_t off[4] = {p00, p00 + C, p00 + (size_t)W * C, p00 + (size_t)W * C + C};
+        const bool ok[4] = {true, pw1, ph1, ph1 && pw1};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!ok[k]) continue;
+            const f32x4 xh = (pp.y[k] - mean) * rstd;
+            *reinterpret_cast<f32x4*>(dy + off[k]) = (pp.g[k] - c2 - xh * c3) * c1;
+        }
     }
 }
 
@@ -589,7 +642,7 @@ int launch_bn_train_fwd(const float* y, int M, int C, const float* gamma, const 
         CILRS_LAUNCH_CHECK();
         nblk = p.nblk;
     }
-    bn_fwd_finalize_kernel<<<cdiv(C, kFinChannels), 64 * kFinChannels, 0, s>>>(partial, nblk, M, C, gamma, beta,
+    bn_fwd_finalize_kernel<<<C, kFinThreads, 0, s>>>(partial, nblk, M, C, gamma, beta,
                                                         running_mean, running_var, nbt, momentum,
                                                         eps, stats);
     CILRS_LAUNCH_CHECK();
@@ -634,7 +687,7 @@ int launch_bn_bwd(const float* dz, const float* z, const float* y, int M, int C,
         CILRS_LAUNCH_CHECK();
         nblk = p.nblk;
     }
-    bn_bwd_finalize_kernel<<<cdiv(C, kFinChannels), 64 * kFinChannels, 0, s>>>(partial, nblk, M, C, gamma, stats,
+    bn_bwd_finalize_kernel<<<C, kFinThreads, 0, s>>>(partial, nblk, M, C, gamma, stats,
                                                         dgamma, dbeta, coef, accumulate);
     CILRS_LAUNCH_CHECK();
     const size_t total4 = (size_t)M * C / 4;
@@ -663,16 +716,23 @@ int launch_bn_bwd_pool(const float* dpool, const unsigned char* argmax, const fl
     CILRS_CHECK(C <= 1024, "bn_bwd_pool: at most 1024 channels (got %d)", C);
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const int M = N * H * W;
-    const ColPlan p = col_plan(M, C);
-    bn_colreduce_pool_kernel<<<p.nblk, 256, 0, s>>>(y, dpool, argmax, stats, partial, N, H, W, C,
-                                                    Ho, Wo, p.rows_per_block);
+    // a block owns consecutive 2x2 patches: <= kMaxPartBlocks blocks, whole iterations of the
+    // 256-thread block (256 / (C/4) patches each)
+    const int NP = N * ((H + 1) / 2) * ((W + 1) / 2);
+    const int ppi = 256 / (C >> 2);
+    int ppb = cdiv(NP, kMaxPartBlocks);
+    if (ppb < 2 * ppi) ppb = 2 * ppi;
+    ppb = cdiv(ppb, ppi) * ppi;
+    const int nblk = cdiv(NP, ppb);
+    bn_colreduce_pool_kernel<<<nblk, 256, 0, s>>>(y, dpool, argmax, stats, partial, N, H, W, C,
+                                                  Ho, Wo, ppb);
     CILRS_LAUNCH_CHECK();
-    bn_bwd_finalize_kernel<<<cdiv(C, kFinChannels), 64 * kFinChannels, 0, s>>>(
-        partial, p.nblk, M, C, gamma, stats, dgamma, dbeta, coef, 0);
+    bn_bwd_finalize_kernel<<<C, kFinThreads, 0, s>>>(partial, nblk, M, C, gamma, stats, dgamma,
+                                                     dbeta, coef, 0);
     CILRS_LAUNCH_CHECK();
-    const size_t total4 = (size_t)M * C / 4;
-    bn_bwd_apply_pool_kernel<<<grid_for(total4), 256, 0, s>>>(y, dpool, argmax, stats, coef, dy, N,
-                                                             H, W, C, Ho, Wo);
+    const size_t total = (size_t)NP * (C / 4);
+    bn_bwd_apply_pool_kernel<<<grid_for(total), 256, 0, s>>>(y, dpool, argmax, stats, coef, dy, N,
+                                                            H, W, C, Ho, Wo);
     CILRS_LAUNCH_CHECK();
     return 0;
 }

@@ -312,14 +312,37 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
             *o = accumulate ? *o + v : v;
         }
     } else {
-        for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n_src;
-             idx += (size_t)gridDim.x * blockDim.x) {
+        // scalar outputs (the channel-padded stem: 12.5 K outputs x up to 512 slabs): the same
+        // G-groups-per-output shape, so ~800 blocks share the slab reads instead of 49
+        __shared__ float red1[256];
+        const int opb = 256 / G;
+        const int g = threadIdx.x / opb, ol = threadIdx.x - g * opb;
+        const size_t idx = (size_t)blockIdx.x * opb + ol;
+        float v = 0.f;
+        if (idx < n_src) {
+            const float* base = slabs + idx;
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            int sidx = g;
+            for (; sidx + 3 * G < splits; sidx += 4 * G) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[u] += base[(size_t)(sidx + u * G) * n_src];
+            }
+            for (; sidx < splits; sidx += G) acc[0] += base[(size_t)sidx * n_src];
+            v = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        }
+        if (G > 1) {
+            red1[threadIdx.x] = v;
+            __syncthreads();
+            if (g == 0) {
+                for (int k = 1; k < G; ++k) v += red1[k * opb + ol];
+            }
+        }
+        if (g == 0 && idx < n_src) {
             const int ci = (int)(idx % cin);
-            if (ci >= cin_dst) continue;
-            float v = slabs[idx];
-            for (int sp = 1; sp < splits; ++sp) v += slabs[(size_t)sp * n_src + idx];
-            const size_t o = (idx / cin) * cin_dst + ci;
-            dw[o] = accumulate ? dw[o] + v : v;
+            if (ci < cin_dst) {
+                const size_t o = (idx / cin) * cin_dst + ci;
+                dw[o] = accumulate ? dw[o] + v : v;
+            }
         }
     }
 }
@@ -447,9 +470,11 @@ int launch_conv_wgrad(const WgradArgs& a, hipStream_t s) {
         wgrad_reduce_kernel<4><<<(int)((nvec + opb - 1) / opb), 256, 0, s>>>(
             a.slabs, a.dw, p.splits, n_src, a.Cin, a.Cin_dst, a.accumulate, G);
     } else {
-        const int blocks = (int)((n_src + 255) / 256 < 1024 ? (n_src + 255) / 256 : 1024);
-        wgrad_reduce_kernel<1><<<blocks, 256, 0, s>>>(a.slabs, a.dw, p.splits, n_src, a.Cin,
-                                                      a.Cin_dst, a.accumulate, 1);
+        int G = 1;
+        while (G < 16 && n_src * G < 262144 && 8 * G <= p.splits) G *= 2;
+        const int opb = 256 / G;
+        wgrad_reduce_kernel<1><<<(int)((n_src + opb - 1) / opb), 256, 0, s>>>(
+            a.slabs, a.dw, p.splits, n_src, a.Cin, a.Cin_dst, a.accumulate, G);
     }
     CILRS_LAUNCH_CHECK();
     return 0;
