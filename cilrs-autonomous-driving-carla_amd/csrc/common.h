@@ -106,6 +106,7 @@ struct ConvArgs {
                            // same tiles fed by LDS-DMA (tests/tuning)
     int force_splitk;      // 0 auto
     int splitk;            // set by the launcher
+    int prio_mode;         // set by the launcher: wave_priority() mode (CILRS_PRIO)
     ConvMulti multi;       // set by launch_conv_dgrad (stride 2)
 };
 int launch_conv_igemm(const ConvArgs& a, hipStream_t s);
@@ -124,6 +125,39 @@ struct DgradArgs {
 };
 int launch_conv_dgrad(const DgradArgs& a, hipStream_t s);
 
+// ---- static wave priorities --------------------------------------------------------------------
+// Blocks that share a CU run the same K loop: [index math, LDS write, barrier, first LDS reads]
+// (~700 cycles with the matrix pipe idle for that wave) then a burst of dependent MFMAs.  With
+// equal priorities the SIMD's arbiter hands the matrix pipe round-robin to every wave that has an
+// MFMA ready, so co-resident waves finish their bursts together and sit out their gaps TOGETHER
+// (tools/occupancy_probe.py: a launch costs KT x (0.29 + 0.46 n) us for n blocks per CU -- the
+// 0.29 never overlaps).  Distinct priorities per co-resident block break the convoy: the highest
+// one runs undisturbed and the others fill its gaps.
+//   mode 1: (blockIdx.x / 256) & 3   -- blocks are dealt to the 256 CUs in order
+//   mode 2: hardware wave slot & 3   -- HW_ID.wave_id, the slot this wave occupies on its SIMD
+#if defined(__HIPCC__)
+__device__ __forceinline__ void wave_priority(const int mode) {
+    if (mode == 0) return;
+    int p;
+    if (mode == 1) p = (int)(blockIdx.x >> 8) & 3;
+    else p = (int)__builtin_amdgcn_s_getreg((3 << 11) | 4) & 3;      // HW_REG_HW_ID[3:0]
+    p = __builtin_amdgcn_readfirstlane(p);
+    if (p == 0) __builtin_amdgcn_s_setprio(0);
+    else if (p == 1) __builtin_amdgcn_s_setprio(1);
+    else if (p == 2) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(3);
+}
+// Experiment (CILRS_PRIO = 16 + units, tools/occupancy_probe.py): instead of priorities, START the
+// co-resident blocks out of phase -- block k of a CU sleeps k x units x 64 cycles before its K loop
+__device__ __forceinline__ void wave_stagger(const int mode) {
+    if (mode < 16) return;
+    const int units = mode - 16;
+    const int k = (int)((blockIdx.x >> 8) % 5u);
+    for (int i = 0; i < k * units; ++i) __builtin_amdgcn_s_sleep(1);
+}
+#endif
+int wave_priority_mode();      // CILRS_PRIO (default: see net.hip)
+
 // ---- weight gradient (conv_wgrad.hip) --------------------------------------------------------
 struct WgradArgs {
     const float* x;        // forward input  [N][H][W] pixels, x_ld apart, Cin used
@@ -136,6 +170,7 @@ struct WgradArgs {
     int x_ld, dy_ld;
     int Cin_dst;           // Cin of dw (3 for the stem whose x is channel-padded to 4)
     int accumulate;        // dw += result instead of dw = result
+    int prio_mode;         // wave_priority() mode; launch_conv_wgrad fills it from CILRS_PRIO
 };
 size_t wgrad_scratch_floats(const WgradArgs& a);
 int launch_conv_wgrad(const WgradArgs& a, hipStream_t s);

@@ -91,6 +91,8 @@ void conv_igemm_kernel(const ConvArgs a, const int M_, const int Krow, const int
     const int l31 = lane & 31, lh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
 
+    wave_priority(a.prio_mode < 16 ? a.prio_mode : 0);
+    wave_stagger(a.prio_mode);
     const int tilesN = a.Cout / BN;
     int logical = xcd_remap(blockIdx.x, gridDim.x);
     // geometry of this block's (sub-)problem
@@ -900,6 +902,7 @@ Choice choose(int M, int Cout, int KT, bool allow_split, int force_cfg, int forc
 
 int launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
     ConvArgs a = a_in;
+    a.prio_mode = wave_priority_mode();
     const int M = a.N * a.Ho * a.Wo;
     const bool uniform = (a.Cin % BK) == 0;
     // the uniform path addresses both operands with 32-bit byte offsets (buffer loads)
@@ -1068,6 +1071,7 @@ int launch_conv_dgrad(const DgradArgs& d, hipStream_t s) {
         c.out_H = d.H; c.out_W = d.W; c.out_sh = 2; c.out_sw = 2; c.out_h0 = c.out_w0 = 0;
         c.Ho = (d.H + 1) / 2; c.Wo = (d.W + 1) / 2;          // class (0,0): never empty
         c.splitk = 1; c.scratch = nullptr; c.tile_counters = nullptr;
+        c.prio_mode = wave_priority_mode();
         struct Cls { int ph, pw, nt, Ho, Wo; int dh[4], dw[4], tw[4]; } cl[4];
         int ncl = 0;
         for (int ph = 0; ph < 2; ++ph)

@@ -43,6 +43,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a, c
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
+    wave_priority(a.prio_mode < 16 ? a.prio_mode : 0);
 
     // 1-D grid over (column tile, co tile, K-slab), column tile fastest.  The hardware deals
     // consecutive block ids round-robin over the 8 XCDs (each with its own L2), so in plain order
@@ -412,7 +413,9 @@ size_t wgrad_scratch_floats(const WgradArgs& a) {
     return (size_t)p.splits * a.Cout * p.ncols;
 }
 
-int launch_conv_wgrad(const WgradArgs& a, hipStream_t s) {
+int launch_conv_wgrad(const WgradArgs& a_in, hipStream_t s) {
+    WgradArgs a = a_in;
+    a.prio_mode = wave_priority_mode();
     CILRS_CHECK(a.Cout % 64 == 0, "conv_wgrad: Cout=%d must be a multiple of 64", a.Cout);
     CILRS_CHECK(a.Cin % 4 == 0 && a.x_ld % 4 == 0 && a.dy_ld % 4 == 0,
                 "conv_wgrad: Cin/x_ld/dy_ld must be multiples of 4");

@@ -31,6 +31,12 @@ void set_error(const char* fmt, ...) {
 }
 const char* last_error() { return g_err; }
 
+// CILRS_PRIO: static wave priorities of the GEMM kernels (common.h wave_priority)
+int wave_priority_mode() {
+    static const int m = getenv("CILRS_PRIO") ? atoi(getenv("CILRS_PRIO")) : 0;
+    return m;
+}
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------
