@@ -187,15 +187,19 @@ class Engine:
         return (a.data_ptr() == self.params.data_ptr() and a.device == self.device
                 and b.device == self.device)
 
-    def plan(self, batch, h, w) -> Plan:
-        key = (batch, h, w)
+    def plan(self, batch, h, w, lane=0) -> Plan:
+        """The cilrs_net + workspace for one (batch, H, W).  `lane` > 0 gives further,
+        independent plans of the same geometry: concurrent inference streams (each on its own
+        HIP stream) must not share a workspace."""
+        key = (batch, h, w) if lane == 0 else (batch, h, w, lane)
         pl = self.plans.get(key)
         if pl is None:
             pl = Plan(self.device, batch, h, w, self.variant)
             self.plans[key] = pl
-            self.bufs[key] = L.Buffers(self.params.data_ptr(), self.grads.data_ptr(),
-                                       self.bn.data_ptr(), self.nbt.data_ptr(),
-                                       pl.workspace.data_ptr())
+            pl.bufs = L.Buffers(self.params.data_ptr(), self.grads.data_ptr(),
+                                self.bn.data_ptr(), self.nbt.data_ptr(),
+                                pl.workspace.data_ptr())
+            self.bufs[key] = pl.bufs
         return pl
 
     def _stream(self):
@@ -241,7 +245,7 @@ class Engine:
             self.weights_epoch += 1           # BN running statistics are about to move
         self._announce_weights(pl)
         L.check(L.lib().cilrs_net_forward(
-            pl.handle, C.byref(self.bufs[(pl.batch, pl.h, pl.w)]), L.ptr(image), sn, sc, sh, sw,
+            pl.handle, C.byref(pl.bufs), L.ptr(image), sn, sc, sh, sw,
             L.ptr(speed), L.ptr(command), 1 if train else 0, float(dropout_p), int(seed),
             L.ptr(controls), L.ptr(pred_speed), self._stream()))
         if train:
@@ -254,16 +258,18 @@ class Engine:
         if self.last_plan is not None:
             self.last_plan.check_status()
 
-    def run_forward_u8(self, frames_u8, speed, command, out=None, graph=False, half=False):
+    def run_forward_u8(self, frames_u8, speed, command, out=None, graph=False, half=False,
+                       lane=0):
         """uint8 RGB HWC frames [B,H,W,3] -> eval forward with fused preprocessing.  With
         graph=True the launch sequence is replayed from a cached hipGraph (all tensors must keep
         their addresses; the current stream must not be the default stream).  half=True / "f16"
         runs the trunk in fp16, half="bf16" in bf16 (BatchNorm folded into 16-bit weights, fp32
-        accumulation): batched serving."""
+        accumulation): batched serving.  Calls issued on different HIP streams at the same time
+        must use different `lane`s (one workspace each)."""
         if frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4 or frames_u8.size(3) != 3:
             raise RuntimeError("frames must be uint8 [B,H,W,3]")
         b = frames_u8.size(0)
-        pl = self.plan(b, frames_u8.size(1), frames_u8.size(2))
+        pl = self.plan(b, frames_u8.size(1), frames_u8.size(2), lane)
         frames_u8 = frames_u8.contiguous()
         if out is None:
             controls = torch.empty(b, 3, dtype=torch.float32, device=self.device)
@@ -278,7 +284,7 @@ class Engine:
         else:
             fn = lib.cilrs_net_forward_u8_graph if graph else lib.cilrs_net_forward_u8
         self._announce_weights(pl)
-        L.check(fn(pl.handle, C.byref(self.bufs[(pl.batch, pl.h, pl.w)]), L.ptr(frames_u8),
+        L.check(fn(pl.handle, C.byref(pl.bufs), L.ptr(frames_u8),
                    L.ptr(speed.contiguous()), L.ptr(command.contiguous()), L.ptr(controls),
                    L.ptr(pred_speed), self._stream()))
         self.last_plan = pl
@@ -300,7 +306,7 @@ class Engine:
         hs, ws, px = frames_u8.size(1), frames_u8.size(2), frames_u8.size(3)
         self._announce_weights(pl)
         L.check(L.lib().cilrs_net_forward_camera(
-            pl.handle, C.byref(self.bufs[(pl.batch, pl.h, pl.w)]), L.ptr(frames_u8), hs, ws, px,
+            pl.handle, C.byref(pl.bufs), L.ptr(frames_u8), hs, ws, px,
             ws * px, hs * ws * px, L.ptr(speed.contiguous()), L.ptr(command.contiguous()),
             L.ptr(controls), L.ptr(pred_speed), self._stream()))
         self.last_plan = pl
@@ -309,7 +315,7 @@ class Engine:
     def run_backward(self, pl, dcontrols, dpred_speed, seg_begin=0, seg_end=6, into=None):
         """Writes the parameter gradients of segments [seg_begin, seg_end) into the gradient
         arena, or into `into` (another arena of the same layout)."""
-        bufs = self.bufs[(pl.batch, pl.h, pl.w)]
+        bufs = pl.bufs
         if into is not None:
             bufs = L.Buffers(self.params.data_ptr(), into.data_ptr(), self.bn.data_ptr(),
                              self.nbt.data_ptr(), pl.workspace.data_ptr())

@@ -1109,3 +1109,32 @@ def test_inference_state_cache_follows_weight_updates():
             m.weights_changed()
             a4 = pr.predict_controls(frame, 30.0, 1)
             assert abs((a4[3] - a3[3]) - 0.25 * 90.0) <= 1e-3 and a4[:3] == a3[:3]
+
+
+def test_concurrent_inference_lanes_match_the_single_plan():
+    """BASELINE configs[4] serving shape: several frame streams in flight at once, each on its
+    own HIP stream with its own lane (plan + workspace).  Every lane returns exactly what the
+    single plan returns for the same frames, eager and from a hipGraph, fp32 and fp16 trunk."""
+    m = make_model().eval()
+    eng = m.engine()
+    B, S = 16, 3
+    u = torch.randint(0, 256, (S, B, 88, 200, 3), dtype=torch.uint8, device="cuda")
+    spd = torch.rand(B, device="cuda")
+    cmd = torch.randint(0, 4, (B,), device="cuda")
+    streams = [torch.cuda.Stream() for _ in range(S)]
+    for half in (False, True):
+        want = [tuple(t.clone() for t in eng.run_forward_u8(u[i], spd, cmd, half=half))
+                for i in range(S)]
+        torch.cuda.synchronize()
+        for graph in (False, True):
+            outs = [(torch.empty(B, 3, device="cuda"), torch.empty(B, device="cuda"))
+                    for _ in range(S)]
+            for _ in range(3):                       # replays too
+                for i in range(S):
+                    with torch.cuda.stream(streams[i]):
+                        eng.run_forward_u8(u[i], spd, cmd, out=outs[i], graph=graph, half=half,
+                                           lane=i + 1)
+            torch.cuda.synchronize()
+            for i in range(S):
+                assert torch.equal(outs[i][0], want[i][0]) and torch.equal(outs[i][1], want[i][1])
+    assert eng.plan(B, 88, 200, 1) is not eng.plan(B, 88, 200) is not eng.plan(B, 88, 200, 2)
