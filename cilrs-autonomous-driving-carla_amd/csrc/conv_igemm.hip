@@ -60,6 +60,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // The register-staged 64x64 tile also uses the unpadded, XOR-swizzled LDS image: 32 KB per block
 // instead of 36.9 KB lets FIVE blocks share a CU (160 KB LDS, <= 96 VGPRs), i.e. 1,280 block slots
 // instead of 1,024 -- layer2's 1,100 tiles then fit in one round.
+// Timing experiments only (tools/igemm_dbg.sh builds side libraries with -DCILRS_IGEMM_DBG=mask; results
+// are numerically meaningless): 1 = no global loads in the K loop, 2 = no LDS stores, 4 = no
+// barriers, 8 = no LDS reads (operands stay in registers)
+#ifndef CILRS_IGEMM_DBG
+#define CILRS_IGEMM_DBG 0
+#endif
 template <int BM, int BN, bool TAP_UNIFORM, bool DMA>
 constexpr bool igemm_swz() { return DMA || (BM == 64 && BN == 64 && TAP_UNIFORM); }
 template <int BM, int BN, bool TAP_UNIFORM, bool DMA>
@@ -227,6 +233,8 @@ void conv_igemm_kernel(const ConvArgs a, const int M_, const int Krow, const int
 #pragma unroll
             for (int i = 0; i < A_PASSES; ++i) {
                 const unsigned off = (rowMask[i] & bit) ? rowOff[i] + toff : 0xFFFFFFFFu;
+                if constexpr (CILRS_IGEMM_DBG & 1) ra[i] = f32x4{(float)off, 1.f, 1.f, 1.f};
+                else
                 ra[i] = __builtin_bit_cast(
                     f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)off, 0, 0));
             }
@@ -234,9 +242,12 @@ void conv_igemm_kernel(const ConvArgs a, const int M_, const int Krow, const int
             if constexpr (W_MODE == 0) koff += (unsigned)(ld_c * BK * 4);
             else koff += (unsigned)(ld_c * BK) * (unsigned)(wrow * 4);
 #pragma unroll
-            for (int i = 0; i < B_PASSES; ++i)
+            for (int i = 0; i < B_PASSES; ++i) {
+                if constexpr (CILRS_IGEMM_DBG & 1) rb[i] = f32x4{(float)(wOff[i] + koff), 1.f, 1.f, 1.f};
+                else
                 rb[i] = __builtin_bit_cast(
                     f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)(wOff[i] + koff), 0, 0));
+            }
         } else if constexpr (TAP_UNIFORM) {
             const long toff = ((long)tap_dh(ld_tap) * a.W + tap_dw(ld_tap)) * a.x_ld +
                               ld_c * BK;
@@ -279,6 +290,10 @@ void conv_igemm_kernel(const ConvArgs a, const int M_, const int Krow, const int
     };
 
     auto store_tile = [&](int buf, const f32x4(&ra)[A_PASSES], const f32x4(&rb)[B_PASSES]) {
+        if constexpr (CILRS_IGEMM_DBG & 2) {
+            asm volatile("" ::"v"(ra[0]), "v"(rb[0]), "v"(ra[A_PASSES - 1]), "v"(rb[B_PASSES - 1]));
+            return;
+        }
         float* Ab = As + buf * BM * APIT;
         float* Bb = Bs + buf * B_FLOATS;
         // swizzled image: logical 16-B chunk kq of row r sits at position kq ^ ((r >> 1) & 7)
@@ -312,6 +327,13 @@ void conv_igemm_kernel(const ConvArgs a, const int M_, const int Krow, const int
         // operand fragments of k-group q+1 are read from LDS while group q is multiplied
         f32x4 af[2][TM], bf[2][TN];
         auto frags = [&](int q, f32x4(&fa)[TM], f32x4(&fb)[TN]) {
+            if constexpr (CILRS_IGEMM_DBG & 8) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[i] = f32x4{(float)q, 1.f, 2.f, 3.f};
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[j] = f32x4{(float)buf, 1.f, 2.f, 3.f};
+                return;
+            }
             const int chunk = SWZ ? (((2 * q + lh) ^ swz) * 4) : (q * 8 + lh * 4);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -392,12 +414,12 @@ void conv_igemm_kernel(const ConvArgs a, const int M_, const int Krow, const int
             __builtin_amdgcn_sched_barrier(0);   // issue the loads BEFORE the multiplies: two
             compute(0);                          // compute phases of latency cover, not one
             store_tile(1, ra1, rb1);
-            __syncthreads();
+            if constexpr (!(CILRS_IGEMM_DBG & 4)) __syncthreads();
             load_tile(ra1, rb1);
             __builtin_amdgcn_sched_barrier(0);
             compute(1);
             store_tile(0, ra0, rb0);
-            __syncthreads();
+            if constexpr (!(CILRS_IGEMM_DBG & 4)) __syncthreads();
         }
     } else {
         if (nt > 0) load_tile(ra0, rb0);

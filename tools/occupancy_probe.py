@@ -16,12 +16,16 @@ from fill_probe import timeit  # noqa: E402
 
 
 def main():
+    cfg = int(os.environ.get("CFG", "2"))          # 2: 64x64 register-staged; 5: 64x64 LDS-DMA; 0: 128x128
+    bm = 128 if cfg in (0, 3) else 64
     lib = L.lib()
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     for C_ in (256, 64):
         kt = 9 * C_ // 32
         for tiles in (64, 128, 256, 384, 512, 640, 768, 896, 1024, 1152, 1280, 1536, 1920, 2560):
-            N = tiles // (C_ // 64)
+            if bm == 128 and (C_ < 128 or tiles > 1024):
+                continue
+            N = tiles // (C_ // bm) * (bm // 64)
             M = N * 64
             x = torch.randn(N, 8, 8, C_, device="cuda")
             w = torch.randn(C_, 3, 3, C_, device="cuda") * 0.05
@@ -30,7 +34,7 @@ def main():
 
             def f():
                 L.check(lib.cilrs_conv2d_fwd(L.ptr(x), L.ptr(w), L.ptr(y), N, 8, 8, C_, C_, 3, 3,
-                                             1, 1, 2, 1, None, 0, st))
+                                             1, 1, cfg, 1, None, 0, st))
             us = timeit(f)
             print(f"C={C_:3d} tiles={tiles:5d} ({tiles / 256:5.2f} per CU) {us:8.1f}us "
                   f"{flops / us / 1e6:6.1f} TF  {(us - 12.0) / kt:6.3f} us per K-tile", flush=True)
