@@ -192,24 +192,51 @@ __global__ __launch_bounds__(256, (BM == 64 ? 2 : 2)) void conv_f16_kernel(const
     }
 
     // ---- epilogue: + folded-BN bias (+ 16-bit residual), ReLU, 16-bit store --------------------
-    const T* res = reinterpret_cast<const T*>(a.residual);
-    T* yout = reinterpret_cast<T*>(a.y);
+    // The accumulator layout gives a lane ONE column and 16 rows: stored directly that is 2-byte
+    // stores in 64-byte runs (and 2-byte residual loads) -- the wide 1x1 convolutions of the
+    // Bottleneck trunk, which write 4x what they read, were bound by exactly that.  So the tile
+    // goes through LDS once (fp32, acc + bias): every thread then owns 8 consecutive columns of
+    // a row -- one 16-byte residual load, one 16-byte store, whole 128-byte lines per 8 lanes.
+    // Same fp32 operation order per element as before: (acc + bias) + residual, ReLU, round.
+    constexpr int SP = BN + 4;                               // staging pitch (floats)
+    float* stage = reinterpret_cast<float*>(smem_raw);      // [BM][SP]; the K loop ended on a barrier
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int co = n0 + wn * (BN / 2) + j * 32 + l31;
-        const float bias = a.bias[co];
+        const int col = wn * (BN / 2) + j * 32 + l31;
+        const float bias = a.bias[n0 + col];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m >= M) continue;
-                float v = acc[i][j][r] + bias;
-                if (res) v += (float)res[(size_t)m * a.Cout + co];
-                if (a.relu) v = fmaxf(v, 0.f);
-                yout[(size_t)m * a.Cout + co] = (T)v;
+                const int row = wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                stage[row * SP + col] = acc[i][j][r] + bias;
             }
         }
+    }
+    __syncthreads();
+    const T* res = reinterpret_cast<const T*>(a.residual);
+    T* yout = reinterpret_cast<T*>(a.y);
+    constexpr int TPR = BN / 8;                              // threads per output row
+    constexpr int RPP = 256 / TPR;                           // rows per pass
+    const int c8 = (tid % TPR) * 8, rsub = tid / TPR;
+#pragma unroll
+    for (int pass = 0; pass < BM / RPP; ++pass) {
+        const int row = pass * RPP + rsub;
+        const int m = m0 + row;
+        if (m >= M) continue;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(&stage[row * SP + c8]);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(&stage[row * SP + c8 + 4]);
+        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        const size_t o = (size_t)m * a.Cout + n0 + c8;
+        if (res) {
+            const v8 rv = *reinterpret_cast<const v8*>(res + o);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+        }
+        v8 ov;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ov[e] = (T)(a.relu ? fmaxf(v[e], 0.f) : v[e]);
+        *reinterpret_cast<v8*>(yout + o) = ov;
     }
 }
 
