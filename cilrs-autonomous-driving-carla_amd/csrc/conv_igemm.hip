@@ -1085,8 +1085,12 @@ int launch_conv_dgrad(const DgradArgs& d, hipStream_t s) {
     // quarter of the K length; launched separately they ran at 52-61 TF).  Classes are ordered by
     // K length, longest first; a class no tap reaches (1x1 / s2) still gets blocks: with zero
     // K-tiles they write the addend (or zeros) through the ordinary epilogue.
+    // ... when a class alone does not fill the chip.  A class that brings a full round of blocks
+    // of its own (the ResNet-50 variant at 176x400: 2,200 tiles per class) runs 36 % FASTER as four
+    // launches with the cost model's own tile per class (tools/conv_bench.py --r50: 257 vs 349 us).
+    const long cls_tiles = (long)cdiv(d.N * ((d.H + 1) / 2) * ((d.W + 1) / 2), 64) * (d.Cin / 64);
     const bool fuse = d.force_cfg < 0 && d.force_splitk <= 0 && (d.Cout % BK) == 0 &&
-                      (d.Cin % 64) == 0;
+                      (d.Cin % 64) == 0 && cls_tiles < 1280;
     if (fuse) {
         ConvArgs c = a;
         c.stride = 1; c.pad = 0;

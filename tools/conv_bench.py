@@ -20,6 +20,24 @@ SHAPES = [  # name, H, W, Cin, Cout, k, stride, pad
     ("layer4.0 s2", 6, 13, 256, 512, 3, 2, 1),
 ]
 
+R50_SHAPES = [  # the ResNet-50 variant at 176x400 (pool output 44x100); run with --r50 --batch 64
+    ("l1 1x1 64>64", 44, 100, 64, 64, 1, 1, 0),
+    ("l1 3x3 64", 44, 100, 64, 64, 3, 1, 1),
+    ("l1 1x1 64>256", 44, 100, 64, 256, 1, 1, 0),
+    ("l1 1x1 256>64", 44, 100, 256, 64, 1, 1, 0),
+    ("l2 1x1 256>128", 44, 100, 256, 128, 1, 1, 0),
+    ("l2 3x3 s2 128", 44, 100, 128, 128, 3, 2, 1),
+    ("l2 1x1 128>512", 22, 50, 128, 512, 1, 1, 0),
+    ("l2 1x1 512>128", 22, 50, 512, 128, 1, 1, 0),
+    ("l2 3x3 128", 22, 50, 128, 128, 3, 1, 1),
+    ("l3 1x1 256>1024", 11, 25, 256, 1024, 1, 1, 0),
+    ("l3 1x1 1024>256", 11, 25, 1024, 256, 1, 1, 0),
+    ("l3 3x3 256", 11, 25, 256, 256, 3, 1, 1),
+    ("l4 1x1 512>2048", 6, 13, 512, 2048, 1, 1, 0),
+    ("l4 1x1 2048>512", 6, 13, 2048, 512, 1, 1, 0),
+    ("l4 3x3 512", 6, 13, 512, 512, 3, 1, 1),
+]
+
 
 def timeit(fn, iters):
     for _ in range(3):
@@ -39,11 +57,12 @@ def main():
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--wgrad-only", action="store_true")
+    ap.add_argument("--r50", action="store_true", help="the ResNet-50 variant's shapes")
     args = ap.parse_args()
     lib = L.lib()
     N = args.batch
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    for name, H, W, Cin, Cout, k, s, p in SHAPES:
+    for name, H, W, Cin, Cout, k, s, p in (R50_SHAPES if args.r50 else SHAPES):
         Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
         x = torch.randn(N, H, W, Cin, device="cuda")
         w = torch.randn(Cout, k, k, Cin, device="cuda") * 0.05
