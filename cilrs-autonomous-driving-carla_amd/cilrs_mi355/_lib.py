@@ -89,6 +89,11 @@ SIGNATURES = {
     "cilrs_conv2d_dgrad": (i32, [vp, vp, vp, vp] + [i32] * 11 + [vp, sz, vp]),
     "cilrs_conv2d_wgrad_scratch_floats": (sz, [i32] * 9),
     "cilrs_conv2d_wgrad": (i32, [vp, vp, vp, vp] + [i32] * 10 + [vp]),
+    "cilrs_conv2d_16_scratch_halfs": (sz, [i32] * 8),
+    "cilrs_conv2d_fwd_16": (i32, [vp, vp, vp, vp] + [i32] * 9 + [vp, vp]),
+    "cilrs_conv2d_dgrad_16": (i32, [vp, vp, vp, vp] + [i32] * 9 + [vp, vp]),
+    "cilrs_conv2d_wgrad_16_scratch_floats": (sz, [i32] * 8),
+    "cilrs_conv2d_wgrad_16": (i32, [vp, vp, vp, vp] + [i32] * 9 + [vp, vp]),
     "cilrs_bn_partial_floats": (sz, [i32]),
     "cilrs_bn_train_fwd": (i32, [vp, i32, i32, vp, vp, vp, vp, vp, f32, f32, vp, i32, vp, vp, vp,
                                  vp]),

@@ -288,7 +288,22 @@ struct ConvF16Args {
     cilrs_half* y;                // [N][Ho][Wo][Cout]
     int N, H, W, Cin, Ho, Wo, Cout, K, stride, pad, relu;
     int bf16;                     // 0: the 16-bit buffers hold fp16, 1: bf16
+    // ---- training use (16-bit operands, fp32 results; launch_conv_f16_train) ----
+    float* y32;                   // [N][Ho][Wo][Cout] fp32 raw result (no bias / ReLU)
+    const float* addend32;        // optional fp32 tensor of y32's shape added to the result
+    float* bn_partial;            // optional per-M-tile column sums / sums of squares of the raw
+                                  // result, channel-major [2][Cout][M-tiles] (as ConvArgs)
+    int up2;                      // 1: x is the output gradient of a stride-2 convolution and the
+                                  // enumerated grid [Ho][Wo] its INPUT: tap (kh', kw') of the
+                                  // flipped filter reads x at ((h + pad - kh) / 2, (w + pad - kw) / 2),
+                                  // kh = K-1-kh', when both differences are even (pad = forward pad)
 };
+// the same implicit GEMM with fp32 output: forward (w = 16-bit copy of the OHWI weights), data
+// gradient (w = transposed, tap-flipped 16-bit copy; stride 1: pad = K-1-pad_fwd; stride 2: up2)
+int launch_conv_f16_train(const ConvF16Args& a, hipStream_t s);
+// wT[ci][K-1-kh][K-1-kw][co] = (16-bit) w[co][kh][kw][ci]
+int launch_transpose_flip_f16(const float* w, void* wT, int Cout, int K, int Cin, int bf16,
+                              hipStream_t s);
 struct FoldF16Table {
     int n;
     int cout[kMaxConvs];
@@ -304,6 +319,18 @@ int launch_fold_bn_f16(const FoldF16Table& t, const float* params, const float* 
 int launch_f32_to_f16(const float* x, void* y, size_t n, int bf16, hipStream_t s);
 int launch_avgpool_f16(const void* x, float* out, int N, int HW, int C, int out_ld, int bf16,
                        hipStream_t s);
+
+// 16-bit weight gradient (wgrad_f16.hip): dw fp32 OHWI from 16-bit NHWC x and dy
+struct WgradF16Args {
+    const void* x;         // [N][H][W][Cin] 16-bit
+    const void* dy;        // [N][Ho][Wo][Cout] 16-bit
+    float* dw;             // [Cout][K][K][Cin] fp32
+    float* slabs;          // wgrad_f16_scratch_floats() floats
+    int N, H, W, Cin, Ho, Wo, Cout, K, stride, pad;
+    int bf16;
+};
+size_t wgrad_f16_scratch_floats(const WgradF16Args& a);
+int launch_wgrad_f16(const WgradF16Args& a, hipStream_t s);
 
 // grouped small GEMMs of the heads (heads_gemm.hip): mode 0 NT (linear forward), 1 NN (input
 // gradient), 2 TN (weight + bias gradient); one launch covers up to five chains

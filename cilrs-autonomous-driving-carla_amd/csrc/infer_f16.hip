@@ -44,7 +44,9 @@ __device__ __forceinline__ f32x16 mfma16(const b8 a, const b8 b, const f32x16 c)
 //           fp16 1.48 vs 0.92 ms): these convolutions have 1-18 K-tiles per block and are bound
 //           by memory-level parallelism, which two fat blocks per CU halve.  Opt-in only
 //           (CILRS_F16_TILE=128).
-template <typename T, int BM, int BN>
+// TRAIN: fp32 raw result (+ fp32 addend, + BatchNorm column partials) instead of the folded
+// 16-bit epilogue, and the stride-2 data-gradient gather (ConvF16Args::up2).
+template <typename T, int BM, int BN, bool TRAIN = false>
 __global__ __launch_bounds__(256, (BM == 64 ? 2 : 2)) void conv_f16_kernel(const ConvF16Args a) {
     typedef typename Vec8<T>::type v8;
     constexpr int TM = BM / 64, TN = BN / 64;          // MFMA tiles per wave
@@ -81,11 +83,25 @@ __global__ __launch_bounds__(256, (BM == 64 ? 2 : 2)) void conv_f16_kernel(const
         if (m < M) {
             const int n = m / HoWo, rem = m - n * HoWo;
             const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
-            const int hb = oh * a.stride - a.pad, wb = ow * a.stride - a.pad;
-            rowOff[i] = (unsigned)((((long)(n * a.H + hb) * a.W + wb) * a.Cin + kq * 8) * 2);
-            for (int t = 0; t < ntaps; ++t) {
-                const int h = hb + t / a.K, w = wb + t % a.K;
-                if (h >= 0 && w >= 0 && h < a.H && w < a.W) rowMask[i] |= 1u << t;
+            if (TRAIN && a.up2) {
+                // parity-matching taps of row (oh + pad) sit at (oh + pad)/2 - kh/2 (see up2)
+                const int bh = oh + a.pad, bw = ow + a.pad;
+                rowOff[i] = (unsigned)((((long)(n * a.H + (bh >> 1)) * a.W + (bw >> 1)) * a.Cin +
+                                        kq * 8) * 2);
+                for (int t = 0; t < ntaps; ++t) {
+                    const int kh = a.K - 1 - t / a.K, kw = a.K - 1 - t % a.K;
+                    const int h2 = bh - kh, w2 = bw - kw;
+                    if (h2 >= 0 && w2 >= 0 && !(h2 & 1) && !(w2 & 1) && (h2 >> 1) < a.H &&
+                        (w2 >> 1) < a.W)
+                        rowMask[i] |= 1u << t;
+                }
+            } else {
+                const int hb = oh * a.stride - a.pad, wb = ow * a.stride - a.pad;
+                rowOff[i] = (unsigned)((((long)(n * a.H + hb) * a.W + wb) * a.Cin + kq * 8) * 2);
+                for (int t = 0; t < ntaps; ++t) {
+                    const int h = hb + t / a.K, w = wb + t % a.K;
+                    if (h >= 0 && w >= 0 && h < a.H && w < a.W) rowMask[i] |= 1u << t;
+                }
             }
         }
     }
@@ -94,7 +110,12 @@ __global__ __launch_bounds__(256, (BM == 64 ? 2 : 2)) void conv_f16_kernel(const
         wOff[i] = (unsigned)(((long)(n0 + r0 + 32 * i) * Krow + kq * 8) * 2);
     int tapA_v = 0, tapB_v = 0;              // per-tap byte offsets, one tap per lane
     if (lane < ntaps) {
-        tapA_v = ((lane / a.K) * a.W + lane % a.K) * a.Cin * 2;
+        if (TRAIN && a.up2) {
+            const int kh = a.K - 1 - lane / a.K, kw = a.K - 1 - lane % a.K;
+            tapA_v = -(((kh >> 1) * a.W + (kw >> 1)) * a.Cin * 2);
+        } else {
+            tapA_v = ((lane / a.K) * a.W + lane % a.K) * a.Cin * 2;
+        }
         tapB_v = lane * a.Cin * 2;
     }
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
@@ -191,6 +212,73 @@ __global__ __launch_bounds__(256, (BM == 64 ? 2 : 2)) void conv_f16_kernel(const
         __syncthreads();
     }
 
+    if constexpr (TRAIN) {
+        // ---- training epilogue: BatchNorm column partials of the raw fp32 tile (rows >= M are
+        // exact zeros; fixed order => deterministic), then the tile through LDS to 16-byte fp32
+        // stores (+ fp32 addend) ----
+        float* stage = reinterpret_cast<float*>(smem_raw);
+        constexpr int SP = BN + 4;
+        if (a.bn_partial != nullptr) {
+            float* red = stage;                           // [2][BN][2]
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = acc[i][j][r];
+                        s1 += v;
+                        s2 = fmaf(v, v, s2);
+                    }
+                s1 += __shfl_xor(s1, 32);
+                s2 += __shfl_xor(s2, 32);
+                if (lh == 0) {
+                    red[(wm * BN + wn * (BN / 2) + j * 32 + l31) * 2] = s1;
+                    red[(wm * BN + wn * (BN / 2) + j * 32 + l31) * 2 + 1] = s2;
+                }
+            }
+            __syncthreads();
+            if (tid < BN) {
+                const float t1 = red[tid * 2] + red[(BN + tid) * 2];
+                const float t2 = red[tid * 2 + 1] + red[(BN + tid) * 2 + 1];
+                const size_t mt = (size_t)(logical / tilesN), nmt = (size_t)((M + BM - 1) / BM);
+                a.bn_partial[(size_t)(n0 + tid) * nmt + mt] = t1;
+                a.bn_partial[(size_t)(a.Cout + n0 + tid) * nmt + mt] = t2;
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = wn * (BN / 2) + j * 32 + l31;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    stage[row * SP + col] = acc[i][j][r];
+                }
+        }
+        __syncthreads();
+        constexpr int TPR = BN / 8, RPP = 256 / TPR;
+        const int c8 = (tid % TPR) * 8, rsub = tid / TPR;
+#pragma unroll
+        for (int pass = 0; pass < BM / RPP; ++pass) {
+            const int row = pass * RPP + rsub;
+            const int m = m0 + row;
+            if (m >= M) continue;
+            f32x4 lo = *reinterpret_cast<const f32x4*>(&stage[row * SP + c8]);
+            f32x4 hi = *reinterpret_cast<const f32x4*>(&stage[row * SP + c8 + 4]);
+            const size_t o = (size_t)m * a.Cout + n0 + c8;
+            if (a.addend32) {
+                lo += *reinterpret_cast<const f32x4*>(a.addend32 + o);
+                hi += *reinterpret_cast<const f32x4*>(a.addend32 + o + 4);
+            }
+            *reinterpret_cast<f32x4*>(a.y32 + o) = lo;
+            *reinterpret_cast<f32x4*>(a.y32 + o + 4) = hi;
+        }
+        return;
+    }
     // ---- epilogue: + folded-BN bias (+ 16-bit residual), ReLU, 16-bit store --------------------
     // The accumulator layout gives a lane ONE column and 16 rows: stored directly that is 2-byte
     // stores in 64-byte runs (and 2-byte residual loads) -- the wide 1x1 convolutions of the
@@ -321,6 +409,65 @@ int launch_conv_f16(const ConvF16Args& a, hipStream_t s) {
                       : launch_conv_f16_cfg<_Float16, 128, 128>(a, M, s);
     return a.bf16 ? launch_conv_f16_cfg<__bf16, 64, 64>(a, M, s)
                   : launch_conv_f16_cfg<_Float16, 64, 64>(a, M, s);
+}
+
+template <typename T>
+static int launch_conv_f16_train_t(const ConvF16Args& a, int M, hipStream_t s) {
+    constexpr size_t lds = (size_t)2 * (64 + 64) * HPITCH * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        CILRS_HIP(hipFuncSetAttribute(
+            reinterpret_cast<const void*>(&conv_f16_kernel<T, 64, 64, true>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    conv_f16_kernel<T, 64, 64, true><<<cdiv(M, 64) * (a.Cout / 64), 256, lds, s>>>(a);
+    CILRS_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_conv_f16_train(const ConvF16Args& a, hipStream_t s) {
+    CILRS_CHECK(a.Cin % HBK == 0 && a.Cout % 64 == 0 && a.K * a.K <= 16,
+                "conv_f16_train: Cin %% 64, Cout %% 64, <= 16 taps");
+    CILRS_CHECK(a.y32 != nullptr && ((uintptr_t)a.y32 & 15) == 0 &&
+                    ((uintptr_t)a.addend32 & 15) == 0,
+                "conv_f16_train: fp32 output missing / misaligned");
+    CILRS_CHECK((size_t)a.N * a.H * a.W * a.Cin * 2 < (1ull << 32), "conv_f16_train: input too large");
+    CILRS_CHECK(!a.up2 || a.stride == 2, "conv_f16_train: up2 is the stride-2 data gradient");
+    const int M = a.N * a.Ho * a.Wo;
+    return a.bf16 ? launch_conv_f16_train_t<__bf16>(a, M, s)
+                  : launch_conv_f16_train_t<_Float16>(a, M, s);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_flip_f16_kernel(const float* __restrict__ w,
+                                                                 T* __restrict__ wT, const int Cout,
+                                                                 const int K, const int Cin) {
+    // one thread per (ci, tap', co): reads are strided, the tensors are small (<= 9.4 MB)
+    const size_t total = (size_t)Cin * K * K * Cout;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i % Cout);
+        size_t r = i / Cout;
+        const int tp = (int)(r % (K * K));
+        const int ci = (int)(r / (K * K));
+        const int kh = K - 1 - tp / K, kw = K - 1 - tp % K;
+        wT[i] = (T)w[(((size_t)co * K + kh) * K + kw) * Cin + ci];
+    }
+}
+
+int launch_transpose_flip_f16(const float* w, void* wT, int Cout, int K, int Cin, int bf16,
+                              hipStream_t s) {
+    const size_t total = (size_t)Cin * K * K * Cout;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    if (bf16)
+        transpose_flip_f16_kernel<__bf16><<<blocks, 256, 0, s>>>(w, reinterpret_cast<__bf16*>(wT),
+                                                                Cout, K, Cin);
+    else
+        transpose_flip_f16_kernel<_Float16><<<blocks, 256, 0, s>>>(
+            w, reinterpret_cast<_Float16*>(wT), Cout, K, Cin);
+    CILRS_LAUNCH_CHECK();
+    return 0;
 }
 
 int launch_fold_bn_f16(const FoldF16Table& t, const float* params, const float* ws, void* w16,

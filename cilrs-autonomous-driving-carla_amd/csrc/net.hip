@@ -1685,6 +1685,88 @@ int cilrs_conv2d_wgrad(const float* x, const float* dy, float* dw, float* scratc
         reinterpret_cast<hipStream_t>(stream));
 }
 
+// ---- the same three convolution operators on the 16-bit matrix pipe (operands rounded to bf16 /
+//      fp16, fp32 accumulation and results): the kernels of the bf16 training mode, op by op ----
+static size_t up8(size_t v) { return (v + 7) / 8 * 8; }
+size_t cilrs_conv2d_16_scratch_halfs(int N, int H, int W, int Cin, int Cout, int K, int stride,
+                                     int pad) {
+    const int Ho = (H + 2 * pad - K) / stride + 1, Wo = (W + 2 * pad - K) / stride + 1;
+    return up8((size_t)N * H * W * Cin) + up8((size_t)N * Ho * Wo * Cout) +
+           2 * up8((size_t)Cout * K * K * Cin);
+}
+
+int cilrs_conv2d_fwd_16(const float* x, const float* w, float* y, float* bn_partial, int N, int H,
+                        int W, int Cin, int Cout, int K, int stride, int pad, int bf16,
+                        void* scratch16, void* stream) {
+    CILRS_CHECK(x && w && y && scratch16, "conv2d_fwd_16: NULL argument");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    cilrs_half* x16 = reinterpret_cast<cilrs_half*>(scratch16);
+    cilrs_half* w16 = x16 + up8((size_t)N * H * W * Cin);
+    if (launch_f32_to_f16(x, x16, (size_t)N * H * W * Cin, bf16, s)) return 1;
+    if (launch_f32_to_f16(w, w16, (size_t)Cout * K * K * Cin, bf16, s)) return 1;
+    ConvF16Args a;
+    memset(&a, 0, sizeof(a));
+    a.x = x16; a.w = w16; a.y32 = y; a.bn_partial = bn_partial;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.K = K; a.stride = stride; a.pad = pad;
+    a.Ho = (H + 2 * pad - K) / stride + 1; a.Wo = (W + 2 * pad - K) / stride + 1;
+    a.bf16 = bf16;
+    return launch_conv_f16_train(a, s);
+}
+
+int cilrs_conv2d_dgrad_16(const float* dy, const float* w, float* dx, const float* addend, int N,
+                          int H, int W, int Cin, int Cout, int K, int stride, int pad, int bf16,
+                          void* scratch16, void* stream) {
+    CILRS_CHECK(dy && w && dx && scratch16, "conv2d_dgrad_16: NULL argument");
+    CILRS_CHECK(stride == 1 || stride == 2, "conv2d_dgrad_16: stride must be 1 or 2");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int Ho = (H + 2 * pad - K) / stride + 1, Wo = (W + 2 * pad - K) / stride + 1;
+    cilrs_half* dy16 = reinterpret_cast<cilrs_half*>(scratch16);
+    cilrs_half* wT16 = dy16 + up8((size_t)N * Ho * Wo * Cout);
+    if (launch_f32_to_f16(dy, dy16, (size_t)N * Ho * Wo * Cout, bf16, s)) return 1;
+    if (launch_transpose_flip_f16(w, wT16, Cout, K, Cin, bf16, s)) return 1;
+    ConvF16Args a;
+    memset(&a, 0, sizeof(a));
+    a.x = dy16; a.w = wT16; a.y32 = dx; a.addend32 = addend;
+    a.N = N; a.H = Ho; a.W = Wo; a.Cin = Cout;       // gathered tensor = dy
+    a.Ho = H; a.Wo = W; a.Cout = Cin;                // enumerated grid = dx
+    a.K = K; a.bf16 = bf16;
+    if (stride == 1) { a.stride = 1; a.pad = K - 1 - pad; }
+    else { a.stride = 2; a.pad = pad; a.up2 = 1; }
+    return launch_conv_f16_train(a, s);
+}
+
+static WgradF16Args make_wgrad16(const void* x16, const void* dy16, float* dw, float* slabs, int N,
+                                 int H, int W, int Cin, int Cout, int K, int stride, int pad,
+                                 int bf16) {
+    WgradF16Args a;
+    memset(&a, 0, sizeof(a));
+    a.x = x16; a.dy = dy16; a.dw = dw; a.slabs = slabs;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.K = K; a.stride = stride; a.pad = pad;
+    a.Ho = (H + 2 * pad - K) / stride + 1; a.Wo = (W + 2 * pad - K) / stride + 1;
+    a.bf16 = bf16;
+    return a;
+}
+
+size_t cilrs_conv2d_wgrad_16_scratch_floats(int N, int H, int W, int Cin, int Cout, int K,
+                                            int stride, int pad) {
+    return wgrad_f16_scratch_floats(
+        make_wgrad16(nullptr, nullptr, nullptr, nullptr, N, H, W, Cin, Cout, K, stride, pad, 1));
+}
+
+int cilrs_conv2d_wgrad_16(const float* x, const float* dy, float* dw, float* scratch32, int N,
+                          int H, int W, int Cin, int Cout, int K, int stride, int pad, int bf16,
+                          void* scratch16, void* stream) {
+    CILRS_CHECK(x && dy && dw && scratch32 && scratch16, "conv2d_wgrad_16: NULL argument");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int Ho = (H + 2 * pad - K) / stride + 1, Wo = (W + 2 * pad - K) / stride + 1;
+    cilrs_half* x16 = reinterpret_cast<cilrs_half*>(scratch16);
+    cilrs_half* dy16 = x16 + up8((size_t)N * H * W * Cin);
+    if (launch_f32_to_f16(x, x16, (size_t)N * H * W * Cin, bf16, s)) return 1;
+    if (launch_f32_to_f16(dy, dy16, (size_t)N * Ho * Wo * Cout, bf16, s)) return 1;
+    return launch_wgrad_f16(
+        make_wgrad16(x16, dy16, dw, scratch32, N, H, W, Cin, Cout, K, stride, pad, bf16), s);
+}
+
 size_t cilrs_bn_partial_floats(int C) { return bn_partial_floats(C); }
 
 int cilrs_bn_train_fwd(const float* y, int M, int C, const float* gamma, const float* beta,

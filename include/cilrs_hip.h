@@ -277,6 +277,28 @@ size_t cilrs_conv2d_wgrad_scratch_floats(int N, int H, int W, int Cin, int Cout,
 int cilrs_conv2d_wgrad(const float* x, const float* dy, float* dw, float* scratch, int N, int H,
                        int W, int Cin, int Cout, int KH, int KW, int stride, int pad,
                        int Cin_dst, void* stream);
+
+/* ---- the same operators on the 16-bit matrix pipe (BASELINE.json configs[3] "bf16 MFMA path",
+ * training side): x / w / dy are fp32 tensors as above, rounded to bf16 (bf16 = 1) or fp16
+ * (bf16 = 0) into `scratch16` (cilrs_conv2d_16_scratch_halfs() 16-bit elements, 16-byte aligned),
+ * multiplied on v_mfma_f32_32x32x16_* with fp32 accumulation; results are fp32.  Cin and Cout
+ * multiples of 64, square filters K x K (<= 16 taps), stride 1 or 2.  Not the reference's
+ * arithmetic (it trains in fp32): checked against the same product of the ROUNDED operands. */
+size_t cilrs_conv2d_16_scratch_halfs(int N, int H, int W, int Cin, int Cout, int K, int stride,
+                                     int pad);
+/* y = conv(x, w); bn_partial (optional): per-64-row-tile column sums / sums of squares of y,
+ * channel-major [2][Cout][ceil(M/64)] */
+int cilrs_conv2d_fwd_16(const float* x, const float* w, float* y, float* bn_partial, int N, int H,
+                        int W, int Cin, int Cout, int K, int stride, int pad, int bf16,
+                        void* scratch16, void* stream);
+int cilrs_conv2d_dgrad_16(const float* dy, const float* w, float* dx, const float* addend, int N,
+                          int H, int W, int Cin, int Cout, int K, int stride, int pad, int bf16,
+                          void* scratch16, void* stream);
+size_t cilrs_conv2d_wgrad_16_scratch_floats(int N, int H, int W, int Cin, int Cout, int K,
+                                            int stride, int pad);
+int cilrs_conv2d_wgrad_16(const float* x, const float* dy, float* dw, float* scratch32, int N,
+                          int H, int W, int Cin, int Cout, int K, int stride, int pad, int bf16,
+                          void* scratch16, void* stream);
 /* nn.BatchNorm2d training forward (+ optional residual add, ReLU); stats: 4*C floats out */
 size_t cilrs_bn_partial_floats(int C);
 int cilrs_bn_train_fwd(const float* y, int M, int C, const float* gamma, const float* beta,

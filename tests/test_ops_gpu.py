@@ -513,3 +513,79 @@ def test_adam_step_matches_torch_adam(clip, gscale):
         assert (v.cpu() - st["exp_avg_sq"]).abs().max() <= 1e-6 * max(1.0, float(st["exp_avg_sq"].abs().max()))
     # and the trajectory really moved by more than the tolerance
     assert (p_ref.detach() - p0).abs().max() >= 4 * lr
+
+
+# ---- the 16-bit matrix pipe (bf16 training mode), op by op ---------------------------------------
+# Operands are rounded to bf16 / fp16 by the entry points; the reference is the SAME product of the
+# rounded operands in float64 (so only the accumulation order differs: fp32 MFMA accumulation over
+# up to 4,608 terms -> 2e-5 of max|ref| like the fp32 kernels, relaxed to 5e-5).
+CONV16_CASES = [  # N, H, W, Cin, Cout, K, stride, pad
+    (3, 9, 14, 64, 64, 3, 1, 1),
+    (2, 12, 10, 64, 128, 3, 2, 1),      # stride-2 3x3 (BasicBlock / Bottleneck down-sampling conv)
+    (2, 11, 13, 128, 64, 1, 1, 0),      # Bottleneck 1x1
+    (2, 11, 13, 64, 256, 1, 2, 0),      # 1x1 stride-2 down-sample branch, odd size
+    (1, 6, 13, 256, 256, 3, 1, 1),
+    (5, 7, 7, 64, 64, 3, 2, 1),         # odd size, stride 2
+]
+
+
+def _round16(t, bf16):
+    return t.to(torch.bfloat16 if bf16 else torch.float16).double()
+
+
+@pytest.mark.parametrize("case", CONV16_CASES)
+@pytest.mark.parametrize("bf16", [1, 0])
+def test_conv16_fwd_dgrad_wgrad(case, bf16):
+    L = _lib()
+    lib = L.lib()
+    N, H, W, Cin, Cout, k, s, p = case
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (k * k * Cin) ** 0.5
+    xr = _round16(x, bf16).requires_grad_(True)
+    wr = _round16(w, bf16).requires_grad_(True)
+    ref = F.conv2d(xr, wr, None, s, p)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    dy = torch.randn(N, Cout, Ho, Wo, generator=g)
+    dyr = _round16(dy, bf16)
+    gx, gw = torch.autograd.grad(ref, (xr, wr), dyr)
+    n16 = lib.cilrs_conv2d_16_scratch_halfs(N, H, W, Cin, Cout, k, s, p)
+    s16 = torch.zeros(n16, dtype=torch.int16, device="cuda")
+    xd, wd, dyd = nhwc(x), ohwi(w), nhwc(dy)
+    M = N * Ho * Wo
+    # forward (+ BatchNorm column partials)
+    y = torch.full((N, Ho, Wo, Cout), float("nan"), device="cuda")
+    nmt = (M + 63) // 64
+    part = torch.full((2 * Cout * nmt,), float("nan"), device="cuda")
+    L.check(lib.cilrs_conv2d_fwd_16(L.ptr(xd), L.ptr(wd), L.ptr(y), L.ptr(part), N, H, W, Cin,
+                                    Cout, k, s, p, bf16, L.ptr(s16), stream()))
+    torch.cuda.synchronize()
+    got = y.cpu().permute(0, 3, 1, 2).double()
+    tol = 5e-5 * float(ref.detach().abs().max())
+    assert torch.isfinite(got).all()
+    assert (got - ref.detach()).abs().max() <= tol
+    pp = part.cpu().double().view(2, Cout, nmt).sum(-1)
+    flat = ref.detach().permute(0, 2, 3, 1).reshape(M, Cout)
+    assert (pp[0] - flat.sum(0)).abs().max() <= 1e-4 * max(1.0, float(flat.sum(0).abs().max()))
+    assert (pp[1] - (flat ** 2).sum(0)).abs().max() <= 1e-4 * float((flat ** 2).sum(0).max())
+    # data gradient, with and without the fp32 addend
+    for with_add in (False, True):
+        add = torch.randn(N, H, W, Cin, generator=g) if with_add else None
+        addd = dev(add) if with_add else None
+        dx = torch.full((N, H, W, Cin), float("nan"), device="cuda")
+        L.check(lib.cilrs_conv2d_dgrad_16(L.ptr(dyd), L.ptr(wd), L.ptr(dx), L.ptr(addd), N, H, W,
+                                          Cin, Cout, k, s, p, bf16, L.ptr(s16), stream()))
+        torch.cuda.synchronize()
+        want = gx.permute(0, 2, 3, 1) + (add.double() if with_add else 0.0)
+        assert torch.isfinite(dx).all()
+        assert (dx.cpu().double() - want).abs().max() <= 5e-5 * float(want.abs().max()), with_add
+    # weight gradient
+    nsl = lib.cilrs_conv2d_wgrad_16_scratch_floats(N, H, W, Cin, Cout, k, s, p)
+    sl = torch.empty(max(nsl, 4), device="cuda")
+    dw = torch.full((Cout, k, k, Cin), float("nan"), device="cuda")
+    L.check(lib.cilrs_conv2d_wgrad_16(L.ptr(xd), L.ptr(dyd), L.ptr(dw), L.ptr(sl), N, H, W, Cin,
+                                      Cout, k, s, p, bf16, L.ptr(s16), stream()))
+    torch.cuda.synchronize()
+    want = gw.permute(0, 2, 3, 1)
+    assert torch.isfinite(dw).all()
+    assert (dw.cpu().double() - want).abs().max() <= 5e-5 * float(want.abs().max())
