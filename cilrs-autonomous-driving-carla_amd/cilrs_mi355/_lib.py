@@ -53,6 +53,7 @@ SIGNATURES = {
                                     C.POINTER(sz)]),
     "cilrs_net_create": (i32, [i32, i32, i32, C.POINTER(vp)]),
     "cilrs_net_create_variant": (i32, [i32, i32, i32, i32, C.POINTER(vp)]),
+    "cilrs_net_create_ex": (i32, [i32, i32, i32, i32, C.c_uint, C.POINTER(vp)]),
     "cilrs_net_destroy": (None, [vp]),
     "cilrs_net_workspace_bytes": (sz, [vp]),
     "cilrs_net_status_offset": (sz, [vp]),

@@ -66,13 +66,17 @@ def _arena_view(arena, off, numel, shape):
     return flat.view(shape)
 
 
+PLAN_BF16_TRAIN = 1       # include/cilrs_hip.h CILRS_PLAN_BF16_TRAIN
+
+
 class Plan:
     """cilrs_net for one (batch, H, W) + its workspace."""
 
-    def __init__(self, device, batch, h, w, variant=0):
+    def __init__(self, device, batch, h, w, variant=0, flags=0):
         lib = L.lib()
         handle = L.vp()
-        L.check(lib.cilrs_net_create_variant(variant, batch, h, w, C.byref(handle)))
+        L.check(lib.cilrs_net_create_ex(variant, batch, h, w, flags, C.byref(handle)))
+        self.flags = flags
         self.handle = handle
         self.batch, self.h, self.w = batch, h, w
         nbytes = lib.cilrs_net_workspace_bytes(handle)
@@ -178,6 +182,10 @@ class Engine:
         self.plans = {}
         self.bufs = {}
         self.last_plan = None
+        # "fp32" (the reference's arithmetic) or "bf16": train-mode trunk convolutions on the bf16
+        # matrix pipe (include/cilrs_hip.h CILRS_PLAN_BF16_TRAIN); set through
+        # Trainer(..., precision=) or directly before the first train-mode forward
+        self.train_precision = "fp32"
         self._scratch_grads = None        # second gradient arena (autograd accumulation only)
         self.weights_epoch = 1            # bumped by every kernel-side write to params / BN buffers
 
@@ -191,10 +199,13 @@ class Engine:
         """The cilrs_net + workspace for one (batch, H, W).  `lane` > 0 gives further,
         independent plans of the same geometry: concurrent inference streams (each on its own
         HIP stream) must not share a workspace."""
+        flags = PLAN_BF16_TRAIN if self.train_precision == "bf16" else 0
         key = (batch, h, w) if lane == 0 else (batch, h, w, lane)
+        if flags:
+            key = key + ("flags", flags)
         pl = self.plans.get(key)
         if pl is None:
-            pl = Plan(self.device, batch, h, w, self.variant)
+            pl = Plan(self.device, batch, h, w, self.variant, flags)
             self.plans[key] = pl
             pl.bufs = L.Buffers(self.params.data_ptr(), self.grads.data_ptr(),
                                 self.bn.data_ptr(), self.nbt.data_ptr(),

@@ -46,10 +46,17 @@ CONFIG_B = TrainConfig(name="B", lr=1e-4, loss="l1", loss_weights=(5.0, 1.0, 1.0
 
 
 class Trainer:
-    def __init__(self, model, cfg: TrainConfig = CONFIG_A, process_group=None):
+    def __init__(self, model, cfg: TrainConfig = CONFIG_A, process_group=None, precision="fp32"):
+        """precision="bf16": BASELINE.json configs[3]'s "bf16 MFMA path" -- the trunk convolutions
+        of the train step multiply bf16 operands (fp32 accumulation); master weights, BatchNorm,
+        heads, loss and Adam stay fp32.  Not the reference's arithmetic: agrees with the fp32 step
+        to bf16 rounding, not to 1e-4."""
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16'")
         self.model = model
         self.cfg = cfg
         self.eng = model.engine()
+        self.eng.train_precision = precision
         dev = self.eng.device
         n = self.eng.n_arena
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)

@@ -18,6 +18,14 @@ namespace {
 
 constexpr int kMaxPartBlocks = 1024;
 
+// optional bf16 shadow of an fp32 tensor (the 16-bit operand of the next convolution in the bf16
+// training mode): 4 elements = 8 bytes per store
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_bf16x4(__bf16* __restrict__ p, const size_t i4, const f32x4 v) {
+    const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    *reinterpret_cast<bf16x4*>(p + i4 * 4) = o;
+}
+
 // partial[0][c][blk] = sum_rows v1, partial[1][c][blk] = sum_rows v2   (channel-major)
 // MODE 0: v1 = y, v2 = y*y                     (forward statistics)
 // MODE 1: v1 = g, v2 = g * (y - mean) * rstd   (backward reductions), g = dz * (z > 0 if relu)
@@ -210,7 +218,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ stats,
                                                        const float* __restrict__ residual,
                                                        float* __restrict__ z, const size_t total4,
-                                                       const int C, const int relu) {
+                                                       const int C, const int relu,
+                                                       __bf16* __restrict__ z16) {
     const int cq = C >> 2;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
          i += (size_t)gridDim.x * blockDim.x) {
@@ -225,6 +234,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
         *reinterpret_cast<f32x4*>(z + i * 4) = v;
+        if (z16) store_bf16x4(z16, i, v);
     }
 }
 
@@ -248,7 +258,8 @@ __global__ __launch_bounds__(kFinThreads) void bn_bwd_finalize_kernel(
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const float* __restrict__ dz, const float* __restrict__ z, const float* __restrict__ y,
     const float* __restrict__ stats, const float* __restrict__ coef, float* __restrict__ dy,
-    float* __restrict__ g_out, const size_t total4, const int C, const int relu) {
+    float* __restrict__ g_out, const size_t total4, const int C, const int relu,
+    __bf16* __restrict__ dy16) {
     const int cq = C >> 2;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4;
          i += (size_t)gridDim.x * blockDim.x) {
@@ -266,7 +277,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
         }
         const f32x4 xh = (*reinterpret_cast<const f32x4*>(y + i * 4) - mean) * rstd;
         if (g_out) *reinterpret_cast<f32x4*>(g_out + i * 4) = g;
-        *reinterpret_cast<f32x4*>(dy + i * 4) = (g - c2 - xh * c3) * c1;
+        const f32x4 d = (g - c2 - xh * c3) * c1;
+        if (dy) *reinterpret_cast<f32x4*>(dy + i * 4) = d;
+        if (dy16) store_bf16x4(dy16, i, d);
     }
 }
 
@@ -374,7 +387,7 @@ __device__ __forceinline__ f32x4 bn_relu4(const f32x4 v, const f32x4 w, const f3
 __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(
     const float* __restrict__ y, const float* __restrict__ stats, float* __restrict__ out,
     unsigned char* __restrict__ argmax, const int N, const int H, const int W, const int C,
-    const int Ho, const int Wo) {
+    const int Ho, const int Wo, __bf16* __restrict__ out16) {
     const int cq = C >> 2;
     const size_t total = (size_t)N * Ho * Wo * cq;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -411,6 +424,7 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(
             }
         }
         *reinterpret_cast<f32x4*>(out + i * 4) = best;
+        if (out16) store_bf16x4(out16, i, best);
         uchar4 a;
         a.x = (unsigned char)bi[0]; a.y = (unsigned char)bi[1];
         a.z = (unsigned char)bi[2]; a.w = (unsigned char)bi[3];
@@ -632,7 +646,7 @@ static int check_c(int C) {
 int launch_bn_train_fwd(const float* y, int M, int C, const float* gamma, const float* beta,
                         float* running_mean, float* running_var, long long* nbt, float momentum,
                         float eps, const float* residual, int relu, float* stats, float* partial,
-                        float* z, int pre_nblk, hipStream_t s) {
+                        float* z, int pre_nblk, hipStream_t s, void* z16) {
     if (check_c(C)) return 1;
     int nblk = pre_nblk;
     if (nblk <= 0) {
@@ -648,7 +662,8 @@ int launch_bn_train_fwd(const float* y, int M, int C, const float* gamma, const 
     CILRS_LAUNCH_CHECK();
     if (z) {
         const size_t total4 = (size_t)M * C / 4;
-        bn_apply_kernel<<<grid_for(total4), 256, 0, s>>>(y, stats, residual, z, total4, C, relu);
+        bn_apply_kernel<<<grid_for(total4), 256, 0, s>>>(y, stats, residual, z, total4, C, relu,
+                                                         reinterpret_cast<__bf16*>(z16));
         CILRS_LAUNCH_CHECK();
     }
     return 0;
@@ -669,7 +684,8 @@ int launch_bn_eval_fwd(const float* y, int M, int C, const float* gamma, const f
                                                       C, stats);
     CILRS_LAUNCH_CHECK();
     const size_t total4 = (size_t)M * C / 4;
-    bn_apply_kernel<<<grid_for(total4), 256, 0, s>>>(y, stats, residual, z, total4, C, relu);
+    bn_apply_kernel<<<grid_for(total4), 256, 0, s>>>(y, stats, residual, z, total4, C, relu,
+                                                     nullptr);
     CILRS_LAUNCH_CHECK();
     return 0;
 }
@@ -677,7 +693,7 @@ int launch_bn_eval_fwd(const float* y, int M, int C, const float* gamma, const f
 int launch_bn_bwd(const float* dz, const float* z, const float* y, int M, int C,
                   const float* gamma, const float* stats, int relu, float* dgamma, float* dbeta,
                   int accumulate, float* coef, float* partial, float* dy, float* g_out,
-                  int pre_nblk, hipStream_t s) {
+                  int pre_nblk, hipStream_t s, void* dy16) {
     if (check_c(C)) return 1;
     int nblk = pre_nblk;
     if (nblk <= 0) {
@@ -692,18 +708,19 @@ int launch_bn_bwd(const float* dz, const float* z, const float* y, int M, int C,
     CILRS_LAUNCH_CHECK();
     const size_t total4 = (size_t)M * C / 4;
     bn_bwd_apply_kernel<<<grid_for(total4), 256, 0, s>>>(dz, z, y, stats, coef, dy, g_out, total4,
-                                                         C, relu);
+                                                         C, relu, reinterpret_cast<__bf16*>(dy16));
     CILRS_LAUNCH_CHECK();
     return 0;
 }
 
 int launch_bn_relu_maxpool_fwd(const float* y, const float* stats, float* out,
-                               unsigned char* argmax, int N, int H, int W, int C, hipStream_t s) {
+                               unsigned char* argmax, int N, int H, int W, int C, hipStream_t s,
+                               void* out16) {
     CILRS_CHECK(C % 4 == 0 && argmax != nullptr, "bn_relu_maxpool: C %% 4, argmax required");
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const size_t total = (size_t)N * Ho * Wo * (C / 4);
-    bn_relu_maxpool_fwd_kernel<<<grid_for(total), 256, 0, s>>>(y, stats, out, argmax, N, H, W, C,
-                                                               Ho, Wo);
+    bn_relu_maxpool_fwd_kernel<<<grid_for(total), 256, 0, s>>>(
+        y, stats, out, argmax, N, H, W, C, Ho, Wo, reinterpret_cast<__bf16*>(out16));
     CILRS_LAUNCH_CHECK();
     return 0;
 }

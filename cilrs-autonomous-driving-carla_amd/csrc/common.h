@@ -182,7 +182,9 @@ size_t bn_partial_floats(int C);
 int launch_bn_train_fwd(const float* y, int M, int C, const float* gamma, const float* beta,
                         float* running_mean, float* running_var, long long* nbt, float momentum,
                         float eps, const float* residual, int relu, float* stats, float* partial,
-                        float* z, int pre_nblk, hipStream_t s);
+                        float* z, int pre_nblk, hipStream_t s, void* z16 = nullptr);
+// (z16 / dy16 / out16: optional bf16 shadow of the fp32 result -- the 16-bit operand of the next
+//  convolution in the bf16 training mode; launch_bn_bwd: dy may then be NULL)
 // eval-mode scale/shift of up to kMaxConvs BatchNorm layers in one launch (offsets in floats);
 // 36 layers in the ResNet-34 network, 53 in the ResNet-50 variant
 constexpr int kMaxConvs = 56;
@@ -202,10 +204,11 @@ int launch_bn_eval_fwd(const float* y, int M, int C, const float* gamma, const f
 int launch_bn_bwd(const float* dz, const float* z, const float* y, int M, int C,
                   const float* gamma, const float* stats, int relu, float* dgamma, float* dbeta,
                   int accumulate, float* coef, float* partial, float* dy, float* g_out,
-                  int pre_nblk, hipStream_t s);
+                  int pre_nblk, hipStream_t s, void* dy16 = nullptr);
 // stem: BatchNorm apply + ReLU + max-pool without materialising the post-BN tensor, and its backward
 int launch_bn_relu_maxpool_fwd(const float* y, const float* stats, float* out,
-                               unsigned char* argmax, int N, int H, int W, int C, hipStream_t s);
+                               unsigned char* argmax, int N, int H, int W, int C, hipStream_t s,
+                               void* out16 = nullptr);
 int launch_bn_bwd_pool(const float* dpool, const unsigned char* argmax, const float* y, int N,
                        int H, int W, int C, const float* gamma, const float* stats, float* dgamma,
                        float* dbeta, float* coef, float* partial, float* dy, hipStream_t s);
@@ -304,6 +307,14 @@ int launch_conv_f16_train(const ConvF16Args& a, hipStream_t s);
 // wT[ci][K-1-kh][K-1-kw][co] = (16-bit) w[co][kh][kw][ci]
 int launch_transpose_flip_f16(const float* w, void* wT, int Cout, int K, int Cin, int bf16,
                               hipStream_t s);
+struct TransposeF16Table {
+    int n;
+    int cout[kMaxConvs], k[kMaxConvs], cin[kMaxConvs];
+    unsigned w[kMaxConvs];        // fp32 weights in the parameter arena (floats)
+    unsigned wT[kMaxConvs];       // 16-bit elements into the transposed-weight arena
+};
+int launch_transpose_flip_f16_all(const TransposeF16Table& t, const float* params, void* wT16,
+                                  int bf16, hipStream_t s);
 struct FoldF16Table {
     int n;
     int cout[kMaxConvs];

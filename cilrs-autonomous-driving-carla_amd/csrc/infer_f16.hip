@@ -470,6 +470,40 @@ int launch_transpose_flip_f16(const float* w, void* wT, int Cout, int K, int Cin
     return 0;
 }
 
+// every convolution's transposed, tap-flipped 16-bit weights in one launch (blockIdx.y = conv)
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_flip_all_kernel(const TransposeF16Table t,
+                                                                 const float* __restrict__ params,
+                                                                 T* __restrict__ wT16) {
+    const int l = blockIdx.y;
+    const int Cout = t.cout[l], K = t.k[l], Cin = t.cin[l];
+    const float* w = params + t.w[l];
+    T* wT = wT16 + t.wT[l];
+    const size_t total = (size_t)Cin * K * K * Cout;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i % Cout);
+        size_t r = i / Cout;
+        const int tp = (int)(r % (K * K));
+        const int ci = (int)(r / (K * K));
+        const int kh = K - 1 - tp / K, kw = K - 1 - tp % K;
+        wT[i] = (T)w[(((size_t)co * K + kh) * K + kw) * Cin + ci];
+    }
+}
+
+int launch_transpose_flip_f16_all(const TransposeF16Table& t, const float* params, void* wT16,
+                                  int bf16, hipStream_t s) {
+    if (t.n <= 0) return 0;
+    if (bf16)
+        transpose_flip_all_kernel<__bf16><<<dim3(64, t.n), 256, 0, s>>>(
+            t, params, reinterpret_cast<__bf16*>(wT16));
+    else
+        transpose_flip_all_kernel<_Float16><<<dim3(64, t.n), 256, 0, s>>>(
+            t, params, reinterpret_cast<_Float16*>(wT16));
+    CILRS_LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_fold_bn_f16(const FoldF16Table& t, const float* params, const float* ws, void* w16,
                        float* bias, int bf16, hipStream_t s) {
     if (bf16)

@@ -297,6 +297,15 @@ struct cilrs_net {
     const void* prep_bufs[3] = {nullptr, nullptr, nullptr};     // params, bn_running, workspace
     bool trained_fwd = false;
     float last_dropout = 0.f;
+    // bf16 training mode (CILRS_PLAN_BF16_TRAIN): the trunk convolutions after the stem multiply
+    // bf16 operands on v_mfma_f32_32x32x16_bf16 (fp32 accumulation, fp32 results); everything
+    // else -- BatchNorm, residual adds, the stem, the heads, loss, Adam, master weights -- stays
+    // fp32.  16-bit shadows (offsets in floats): whole parameter arena, transposed flipped conv
+    // weights, every post-BN activation, the max-pool output, the dy ring.
+    bool bf16_train = false;
+    size_t w16_all = 0, wT16 = 0, pool16 = 0, slabs16 = 0, slabs16_floats = 0;
+    size_t z16[kMaxConvs] = {}, wT16_off[kMaxConvs] = {}, G16[kNumG] = {};
+    TransposeF16Table tr_table;
     Prof prof;
 };
 
@@ -469,6 +478,68 @@ int conv_wgrad(cilrs_net* net, const ConvT& c, const ConvG& g, const float* x, i
     return 0;
 }
 
+cilrs_half* h16(float* ws, size_t off_floats) {
+    return reinterpret_cast<cilrs_half*>(ws + off_floats);
+}
+
+// the same three operators on the bf16 matrix pipe (bf16 training mode); profile labels as above
+int conv_fwd16(cilrs_net* net, const ConvT& c, const ConvG& g, int ci, const cilrs_half* x16,
+               float* y, float* ws, hipStream_t s, int* bn_nblk) {
+    ConvF16Args a;
+    memset(&a, 0, sizeof(a));
+    a.x = x16; a.w = h16(ws, net->w16_all) + c.w; a.y32 = y;
+    a.bn_partial = ws + net->bn_partial;
+    a.N = net->B; a.H = g.H; a.W = g.W; a.Cin = c.cin; a.Ho = g.Ho; a.Wo = g.Wo; a.Cout = c.cout;
+    a.K = c.k; a.stride = c.stride; a.pad = c.pad; a.bf16 = 1;
+    *bn_nblk = cdiv(g.M, 64);
+    (void)ci;
+    const double flops = 2.0 * g.M * c.cout * c.k * c.k * c.cin;
+    const double bytes = 2.0 * ((double)net->B * g.H * g.W * c.cin + (double)c.cout * c.k * c.k * c.cin) +
+                         4.0 * (double)g.M * c.cout;
+    RUN(net, std::string("conv_fwd.") + kGroupName[c.group], flops, bytes, s,
+        launch_conv_f16_train(a, s));
+    return 0;
+}
+
+int conv_dgrad16(cilrs_net* net, const ConvT& c, const ConvG& g, int ci, const cilrs_half* dy16,
+                 float* dx, const float* addend, float* ws, hipStream_t s) {
+    ConvF16Args a;
+    memset(&a, 0, sizeof(a));
+    a.x = dy16; a.w = h16(ws, net->wT16) + net->wT16_off[ci]; a.y32 = dx; a.addend32 = addend;
+    a.N = net->B; a.H = g.Ho; a.W = g.Wo; a.Cin = c.cout;      // gathered tensor = dy
+    a.Ho = g.H; a.Wo = g.W; a.Cout = c.cin;                    // enumerated grid = dx
+    a.K = c.k; a.bf16 = 1;
+    if (c.stride == 1) { a.stride = 1; a.pad = c.k - 1 - c.pad; }
+    else { a.stride = 2; a.pad = c.pad; a.up2 = 1; }
+    const double flops = 2.0 * g.M * c.cout * c.k * c.k * c.cin;
+    const double bytes = 2.0 * ((double)g.M * c.cout + (double)c.cout * c.k * c.k * c.cin) +
+                         4.0 * (double)net->B * g.H * g.W * c.cin;
+    RUN(net, std::string("conv_dgrad.") + kGroupName[c.group], flops, bytes, s,
+        launch_conv_f16_train(a, s));
+    return 0;
+}
+
+WgradF16Args wgrad16_args(const cilrs_net* net, const ConvT& c, const ConvG& g) {
+    WgradF16Args a;
+    memset(&a, 0, sizeof(a));
+    a.N = net->B; a.H = g.H; a.W = g.W; a.Cin = c.cin; a.Ho = g.Ho; a.Wo = g.Wo; a.Cout = c.cout;
+    a.K = c.k; a.stride = c.stride; a.pad = c.pad; a.bf16 = 1;
+    return a;
+}
+
+int conv_wgrad16(cilrs_net* net, const ConvT& c, const ConvG& g, const cilrs_half* x16,
+                 const cilrs_half* dy16, float* dw, float* ws, hipStream_t s) {
+    WgradF16Args a = wgrad16_args(net, c, g);
+    a.x = x16; a.dy = dy16; a.dw = dw; a.slabs = ws + net->slabs16;
+    CILRS_CHECK(wgrad_f16_scratch_floats(a) <= net->slabs16_floats, "wgrad16 scratch too small");
+    const double flops = 2.0 * g.M * c.cout * c.k * c.k * c.cin;
+    const double bytes = 2.0 * ((double)net->B * g.H * g.W * c.cin + (double)g.M * c.cout) +
+                         4.0 * (double)c.cout * c.k * c.k * c.cin;
+    RUN(net, std::string("conv_wgrad.") + kGroupName[c.group], flops, bytes, s,
+        launch_wgrad_f16(a, s));
+    return 0;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -562,7 +633,13 @@ int cilrs_net_create(int batch, int height, int width, cilrs_net** out) {
 }
 
 int cilrs_net_create_variant(int variant, int batch, int height, int width, cilrs_net** out) {
+    return cilrs_net_create_ex(variant, batch, height, width, 0u, out);
+}
+
+int cilrs_net_create_ex(int variant, int batch, int height, int width, unsigned flags,
+                        cilrs_net** out) {
     CILRS_CHECK(out != nullptr, "cilrs_net_create: out is NULL");
+    CILRS_CHECK((flags & ~1u) == 0, "cilrs_net_create: unknown flags 0x%x", flags);
     CILRS_CHECK(variant_ok(variant), "cilrs_net_create: variant %d out of range", variant);
     CILRS_CHECK(batch >= 1 && height >= 32 && width >= 32, "cilrs_net_create: bad geometry %d %d %d",
                 batch, height, width);
@@ -740,6 +817,29 @@ int cilrs_net_create_variant(int variant, int batch, int height, int width, cilr
         n->f16_act_floats = (actmax + 1) / 2;                              // largest trunk tensor
         for (int k = 0; k < 5; ++k) n->f16_act[k] = bump.take(n->f16_act_floats);
     }
+    if (flags & 1u) {        // CILRS_PLAN_BF16_TRAIN: 16-bit shadows of the training tensors
+        n->bf16_train = true;
+        n->w16_all = bump.take((A.arena_floats + 1) / 2);
+        size_t halfs = 0, sl = 0;
+        n->tr_table.n = 0;
+        for (size_t ci = 1; ci < A.convs.size(); ++ci) {
+            const ConvT& c = A.convs[ci];
+            const int e = n->tr_table.n++;
+            n->tr_table.cout[e] = c.cout; n->tr_table.k[e] = c.k; n->tr_table.cin[e] = c.cin;
+            n->tr_table.w[e] = (unsigned)c.w;
+            n->tr_table.wT[e] = (unsigned)halfs;
+            n->wT16_off[ci] = halfs;
+            halfs += ((size_t)c.cout * c.k * c.k * c.cin + 7) / 8 * 8;
+            n->z16[ci] = bump.take(((size_t)n->cg[ci].M * c.cout + 1) / 2);
+            const size_t f = wgrad_f16_scratch_floats(wgrad16_args(n, c, n->cg[ci]));
+            if (f > sl) sl = f;
+        }
+        n->wT16 = bump.take((halfs + 1) / 2);
+        n->pool16 = bump.take(((size_t)B * n->H1 * n->W1 * 64 + 1) / 2);
+        for (int i = 0; i < kNumG; ++i) n->G16[i] = bump.take((gmax + 1) / 2);
+        n->slabs16_floats = sl;
+        n->slabs16 = bump.take(sl > 0 ? sl : 4);
+    }
     n->ws_bytes = bump.off * sizeof(float);
     *out = n;
     return 0;
@@ -785,6 +885,7 @@ static int forward_from_x4(cilrs_net* net, const cilrs_buffers* bufs, const floa
     float* R = bufs->bn_running;
     const int B = net->B;
     const float eps = 1e-5f, mom = 0.1f;
+    const bool bf16t = train && net->bf16_train;      // trunk convolutions on the bf16 matrix pipe
 
     auto bn = [&](int ci, const float* residual, int relu, int pre_nblk) -> int {
         const ConvT& c = A.convs[ci];
@@ -796,7 +897,8 @@ static int forward_from_x4(cilrs_net* net, const cilrs_buffers* bufs, const floa
                 launch_bn_train_fwd(ws + g.y, g.M, c.cout, P + b.gamma, P + b.beta, R + b.rm,
                                     R + b.rv, reinterpret_cast<long long*>(bufs->bn_nbt) + c.bn,
                                     mom, eps, residual, relu, ws + g.stats, ws + net->bn_partial,
-                                    ws + g.z, pre_nblk, s));
+                                    ws + g.z, pre_nblk, s,
+                                    bf16t ? (void*)h16(ws, net->z16[ci]) : nullptr));
         } else {
             RUN(net, std::string("bn_fwd.") + kGroupName[c.group], 0.0, bytes, s,
                 launch_bn_eval_fwd(ws + g.y, g.M, c.cout, P + b.gamma, P + b.beta, R + b.rm,
@@ -836,28 +938,48 @@ static int forward_from_x4(cilrs_net* net, const cilrs_buffers* bufs, const floa
         unsigned char* argmax = reinterpret_cast<unsigned char*>(bufs->workspace) + net->argmax_b;
         RUN(net, "maxpool", 0.0, 4.0 * net->cg[0].M * 64 * 1.25, s,
             launch_bn_relu_maxpool_fwd(ws + net->cg[0].y, ws + net->cg[0].stats, ws + net->pool,
-                                       argmax, B, net->H0, net->W0, 64, s));
+                                       argmax, B, net->H0, net->W0, 64, s,
+                                       bf16t ? (void*)h16(ws, net->pool16) : nullptr));
+        if (bf16t) {
+            // this step's 16-bit weights: the whole arena (same offsets as fp32) and the
+            // transposed, tap-flipped copies the data gradients read
+            RUN(net, "transform", 0.0, 6.0 * A.arena_floats, s,
+                launch_f32_to_f16(P, h16(ws, net->w16_all), A.arena_floats, 1, s));
+            RUN(net, "transform", 0.0, 0.0, s,
+                launch_transpose_flip_f16_all(net->tr_table, P, h16(ws, net->wT16), 1, s));
+        }
         // ---- residual blocks: BasicBlock conv-BN-ReLU-conv-BN-(+id)-ReLU, Bottleneck with a third
         //      conv-BN pair; the identity (or downsample branch) joins at the last BatchNorm ----
         cur = ws + net->pool;
+        const cilrs_half* cur16 = h16(ws, net->pool16);
         for (const BlockT& blk : A.blocks) {
             const int chain[3] = {blk.conv1, blk.conv2, blk.conv3};
             const int nchain = blk.conv3 >= 0 ? 3 : 2;
             const float* identity = cur;
             const float* x = cur;
+            const cilrs_half* x16 = cur16;
             for (int i = 0; i < nchain; ++i) {
                 const ConvT& c = A.convs[chain[i]];
                 const ConvG& g = net->cg[chain[i]];
                 nb = 0;
-                if (conv_fwd(net, c, g, x, c.cin, P + c.w, ws + g.y, ws, s, &nb)) return 1;
+                if (bf16t) {
+                    if (conv_fwd16(net, c, g, chain[i], x16, ws + g.y, ws, s, &nb)) return 1;
+                } else {
+                    if (conv_fwd(net, c, g, x, c.cin, P + c.w, ws + g.y, ws, s, &nb)) return 1;
+                }
                 if (i == 0 && blk.down >= 0) {
                     // (issued after conv1 so that both convolutions reading `cur` are adjacent)
                     if (bn(chain[0], nullptr, 1, nb)) return 1;
                     const ConvT& cd = A.convs[blk.down];
                     const ConvG& gd = net->cg[blk.down];
                     nb = 0;
-                    if (conv_fwd(net, cd, gd, cur, cd.cin, P + cd.w, ws + gd.y, ws, s, &nb))
-                        return 1;
+                    if (bf16t) {
+                        if (conv_fwd16(net, cd, gd, blk.down, cur16, ws + gd.y, ws, s, &nb))
+                            return 1;
+                    } else {
+                        if (conv_fwd(net, cd, gd, cur, cd.cin, P + cd.w, ws + gd.y, ws, s, &nb))
+                            return 1;
+                    }
                     if (bn(blk.down, nullptr, 0, nb)) return 1;
                     identity = ws + gd.z;
                 } else if (i + 1 < nchain) {
@@ -866,8 +988,10 @@ static int forward_from_x4(cilrs_net* net, const cilrs_buffers* bufs, const floa
                     if (bn(chain[i], identity, 1, nb)) return 1;
                 }
                 x = ws + g.z;
+                x16 = h16(ws, net->z16[chain[i]]);
             }
             cur = x;
+            cur16 = x16;
         }
     } else {
         // eval: running statistics -> per-channel scale/shift (one launch for all 36 layers),
@@ -1305,13 +1429,35 @@ int cilrs_net_backward(cilrs_net* net, const cilrs_buffers* bufs, const float* d
                 float* Gc = ws + net->G[2];
                 const std::string grp = kGroupName[c1.group];
                 // weight gradients run on side stream 0, concurrently with the data gradients
-                auto wgrad_side = [&](const ConvT& c, const ConvG& g, const float* x, int gi,
-                                      float* dwdst) -> int {
+                const bool bf16t = net->bf16_train;
+                // (x: the conv's input activation; x16: its bf16 shadow)
+                auto wgrad_side = [&](const ConvT& c, const ConvG& g, const float* x,
+                                      const cilrs_half* x16, int gi, float* dwdst) -> int {
                     if (gbuf_side_begin(net, s)) return 1;
-                    if (conv_wgrad(net, c, g, x, c.cin, ws + net->G[gi], dwdst, ws,
-                                   side_or(net, s, 0))) return 1;
+                    if (bf16t) {
+                        if (conv_wgrad16(net, c, g, x16, h16(ws, net->G16[gi]), dwdst, ws,
+                                         side_or(net, s, 0))) return 1;
+                    } else {
+                        if (conv_wgrad(net, c, g, x, c.cin, ws + net->G[gi], dwdst, ws,
+                                       side_or(net, s, 0))) return 1;
+                    }
                     return gbuf_side_end(net, gi);
                 };
+                // data gradient of conv `ci`: dy (ring slot gi) -> dx (+ addend)
+                auto dgrad = [&](int ci, int gi, float* dx, const float* addend,
+                                 const ConvG* bn_of, int* nbp) -> int {
+                    const ConvT& c = A.convs[ci];
+                    const ConvG& g = net->cg[ci];
+                    if (bf16t) {
+                        if (nbp) *nbp = 0;       // BatchNorm reduces its own columns in this mode
+                        return conv_dgrad16(net, c, g, ci, h16(ws, net->G16[gi]), dx, addend, ws, s);
+                    }
+                    return conv_dgrad(net, c, g, ws + net->G[gi], P + c.w, dx, addend, ws, s, bn_of,
+                                      1, nbp);
+                };
+                auto z16_of = [&](int ci) { return h16(ws, net->z16[ci]); };
+                const cilrs_half* xin16 =
+                    bi == 0 ? h16(ws, net->pool16) : z16_of(last_conv(A.blocks[bi - 1]));
                 auto next_ring = [&]() {
                     const int gi = kRingIdx[net->dy_pos];
                     net->dy_pos = (net->dy_pos + 1) % dy_ring_depth();
@@ -1328,8 +1474,9 @@ int cilrs_net_backward(cilrs_net* net, const cilrs_buffers* bufs, const float* d
                     RUN(net, "bn_bwd." + grp, 0.0, 4.0 * gl.M * cl.cout * 8.0, s,
                         launch_bn_bwd(Gd, ws + gl.z, ws + gl.y, gl.M, cl.cout, P + bl.gamma,
                                       ws + gl.stats, 1, Gp + bl.gamma, Gp + bl.beta, 0,
-                                      ws + net->bn_coef, ws + net->bn_partial, Ga, Gb,
-                                      net->bwd_nblk_next, s));
+                                      ws + net->bn_coef, ws + net->bn_partial,
+                                      bf16t ? nullptr : Ga, Gb, net->bwd_nblk_next, s,
+                                      bf16t ? (void*)h16(ws, net->G16[ga]) : nullptr));
                     net->bwd_nblk_next = 0;
                 }
                 // 2. walk the main branch backwards: dW_i (side), d(input of conv_i) -> Gc, then
@@ -1340,33 +1487,32 @@ int cilrs_net_backward(cilrs_net* net, const cilrs_buffers* bufs, const float* d
                     const ConvT& cp = A.convs[chain[i - 1]];
                     const ConvG& gp = net->cg[chain[i - 1]];
                     const BnT& bp = A.bns[cp.bn];
-                    if (wgrad_side(c, g, ws + gp.z, ga, Gp + c.w)) return 1;
+                    if (wgrad_side(c, g, ws + gp.z, z16_of(chain[i - 1]), ga, Gp + c.w)) return 1;
                     if (gbuf_acquire(net, s, 2)) return 1;
                     int nbp = 0;    // the previous BatchNorm's reductions ride on this dgrad's epilogue
-                    if (conv_dgrad(net, c, g, Ga, P + c.w, Gc, nullptr, ws, s, &gp, 1, &nbp))
-                        return 1;
+                    if (dgrad(chain[i], ga, Gc, nullptr, &gp, &nbp)) return 1;
                     ga = next_ring();
                     if (gbuf_acquire(net, s, ga)) return 1;
                     Ga = ws + net->G[ga];
                     RUN(net, "bn_bwd." + grp, 0.0, 4.0 * gp.M * cp.cout * 7.0, s,
                         launch_bn_bwd(Gc, ws + gp.z, ws + gp.y, gp.M, cp.cout, P + bp.gamma,
                                       ws + gp.stats, 1, Gp + bp.gamma, Gp + bp.beta, 0,
-                                      ws + net->bn_coef, ws + net->bn_partial, Ga, nullptr, nbp,
-                                      s));
+                                      ws + net->bn_coef, ws + net->bn_partial,
+                                      bf16t ? nullptr : Ga, nullptr, nbp, s,
+                                      bf16t ? (void*)h16(ws, net->G16[ga]) : nullptr));
                 }
                 // 3. dW1 (side)
-                if (wgrad_side(c1, g1, xin, ga, Gp + c1.w)) return 1;
+                if (wgrad_side(c1, g1, xin, xin16, ga, Gp + c1.w)) return 1;
                 if (blk.down < 0) {
                     // 4. dx = dgrad(conv1) + identity grad (Gb) -> Gd
                     // ... and carries the reductions of the previous block's last BatchNorm
                     const ConvG* prev = bi > 0 ? &net->cg[last_conv(A.blocks[bi - 1])] : nullptr;
-                    if (conv_dgrad(net, c1, g1, Ga, P + c1.w, Gd, Gb, ws, s, prev, 1,
-                                   &net->bwd_nblk_next)) return 1;
+                    if (dgrad(blk.conv1, ga, Gd, Gb, prev, &net->bwd_nblk_next)) return 1;
                 } else {
                     const ConvT& cd = A.convs[blk.down];
                     const ConvG& gd = net->cg[blk.down];
                     const BnT& bd = A.bns[cd.bn];
-                    if (conv_dgrad(net, c1, g1, Ga, P + c1.w, Gd, nullptr, ws, s)) return 1;
+                    if (dgrad(blk.conv1, ga, Gd, nullptr, nullptr, nullptr)) return 1;
                     // 5. identity = bn_d(conv_d(x)) (no ReLU): dy_d -> a dy buffer
                     const int gdn = next_ring();
                     if (gbuf_acquire(net, s, gdn)) return 1;
@@ -1374,10 +1520,12 @@ int cilrs_net_backward(cilrs_net* net, const cilrs_buffers* bufs, const float* d
                     RUN(net, "bn_bwd." + grp, 0.0, 4.0 * gd.M * cd.cout * 6.0, s,
                         launch_bn_bwd(Gb, nullptr, ws + gd.y, gd.M, cd.cout, P + bd.gamma,
                                       ws + gd.stats, 0, Gp + bd.gamma, Gp + bd.beta, 0,
-                                      ws + net->bn_coef, ws + net->bn_partial, Gdn, nullptr, 0, s));
-                    if (wgrad_side(cd, gd, xin, gdn, Gp + cd.w)) return 1;
+                                      ws + net->bn_coef, ws + net->bn_partial,
+                                      bf16t ? nullptr : Gdn, nullptr, 0, s,
+                                      bf16t ? (void*)h16(ws, net->G16[gdn]) : nullptr));
+                    if (wgrad_side(cd, gd, xin, xin16, gdn, Gp + cd.w)) return 1;
                     // 6. dx += dgrad(conv_d)
-                    if (conv_dgrad(net, cd, gd, Gdn, P + cd.w, Gd, Gd, ws, s)) return 1;
+                    if (dgrad(blk.down, gdn, Gd, Gd, nullptr, nullptr)) return 1;
                 }
             }
             // the segment's weight gradients are complete when this call returns its work

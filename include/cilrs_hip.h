@@ -82,6 +82,16 @@ typedef struct {
 /* plan for a fixed batch / frame size (reference: B x 3 x 88 x 200) */
 int cilrs_net_create(int batch, int height, int width, cilrs_net** out);
 int cilrs_net_create_variant(int variant, int batch, int height, int width, cilrs_net** out);
+/* The same with plan options.  CILRS_PLAN_BF16_TRAIN: "bf16 MFMA path" training (BASELINE.json
+ * configs[3]) -- in train mode the trunk convolutions after the stem (forward, data gradient,
+ * weight gradient) multiply bf16-rounded activations / weights / output gradients on
+ * v_mfma_f32_32x32x16_bf16 with fp32 accumulation; BatchNorm, residual adds, the stem, the heads,
+ * the loss, Adam and the master weights stay fp32.  Not the reference's arithmetic (it trains in
+ * fp32): outputs and gradients agree with the fp32 path to bf16 rounding (~1e-2), not to 1e-4.
+ * Eval-mode entry points are unaffected.  The workspace grows by the 16-bit shadow tensors. */
+#define CILRS_PLAN_BF16_TRAIN 1u
+int cilrs_net_create_ex(int variant, int batch, int height, int width, unsigned flags,
+                        cilrs_net** out);
 void cilrs_net_destroy(cilrs_net* net);
 size_t cilrs_net_workspace_bytes(const cilrs_net* net);
 
