@@ -565,7 +565,54 @@ def main():
             "gflop_per_frame": round(cfl / b50t / 1e9, 2),
             "device_ms_by_kernel": {k: round(v["ms"] / 2, 3) for k, v in
                                     sorted(tt.items(), key=lambda kv: -kv[1]["ms"])[:12]}}
-        del m50, eng50, tr50, plt, batch50
+        del tr50, plt
+        torch.cuda.empty_cache()
+        # ... and on the bf16 matrix pipe (Trainer(precision="bf16"): trunk convolutions of the
+        # step multiply bf16 operands, fp32 accumulation; BatchNorm / heads / Adam / master
+        # weights fp32) -- BASELINE configs[3] as stated, one GPU's share
+        def bf16_leg(model, batch_t, tag, steps=5):
+            trb = Trainer(model, _CA, precision="bf16")
+            for _ in range(2):
+                trb.train_step(*batch_t)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                trb.train_step(*batch_t)
+            torch.cuda.synchronize(dev)
+            dtb = (time.perf_counter() - t0) / steps
+            lb = trb.losses()
+            b, _, hh, ww = batch_t[0].shape
+            plb = trb.eng.plan(b, hh, ww)
+            plb.profile_reset()
+            plb.profile(True)
+            for _ in range(2):
+                trb.train_step(*batch_t)
+            torch.cuda.synchronize(dev)
+            tb = plb.profile_table()
+            plb.profile(False)
+            convb = [v for k, v in tb.items() if k.startswith("conv_") and not k.endswith(".stem")]
+            cmsb = sum(v["ms"] for v in convb) / 2
+            cflb = sum(v["flops"] for v in convb) / 2
+            return {"workload": tag, "frames_per_s": round(b / dtb, 1),
+                    "ms_per_step": round(dtb * 1e3, 3), "dtype": "bf16 operands, f32 accumulate",
+                    "final_loss": round(lb["total"], 6),
+                    "conv_tflops": round(cflb / max(cmsb, 1e-9) / 1e9, 1),
+                    "conv_frac_of_bf16_matrix_peak": round(cflb / max(cmsb, 1e-9) / 1e9 / 2500.0, 4),
+                    "device_ms_by_kernel": {k: round(v["ms"] / 2, 3) for k, v in
+                                            sorted(tb.items(), key=lambda kv: -kv[1]["ms"])[:12]}}
+        torch.manual_seed(0)
+        m50b = CILRSResNet50(4, 0.0).to(dev)
+        out["resnet50_train_bf16"] = bf16_leg(
+            m50b, batch50, f"CILRS ResNet-50 variant train step, Config A, 176x400 RGB, "
+                           f"B={b50t}, bf16 matrix pipe, random-init weights, synthetic batch")
+        del m50b, m50, eng50, batch50
+        torch.cuda.empty_cache()
+        torch.manual_seed(0)
+        m34b = CILRS(4, dropout=0.0).to(dev)
+        out["train_bf16"] = bf16_leg(
+            m34b, batch, f"CILRS ResNet-34 train step, Config A, 200x88 RGB, B={args.batch}, bf16 "
+                         f"matrix pipe (NOT the headline: the reference's arithmetic is fp32)")
+        del m34b
         torch.cuda.empty_cache()
 
     if want_parity:

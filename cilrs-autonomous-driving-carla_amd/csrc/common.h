@@ -296,6 +296,11 @@ struct ConvF16Args {
     const float* addend32;        // optional fp32 tensor of y32's shape added to the result
     float* bn_partial;            // optional per-M-tile column sums / sums of squares of the raw
                                   // result, channel-major [2][Cout][M-tiles] (as ConvArgs)
+    // optional (data gradient, stride 1): BatchNorm-backward reductions of the layer whose output
+    // gradient this launch produces, per M-tile [2][Cout] partials of g and g * xhat with
+    // g = result * (z > 0 if bwd_relu), xhat = (y - mean) * rstd  (as ConvArgs::bwd_*)
+    const float* bwd_z; const float* bwd_y; const float* bwd_stats; int bwd_relu;
+    float* bwd_partial;
     int up2;                      // 1: x is the output gradient of a stride-2 convolution and the
                                   // enumerated grid [Ho][Wo] its INPUT: tap (kh', kw') of the
                                   // flipped filter reads x at ((h + pad - kh) / 2, (w + pad - kw) / 2),
@@ -312,6 +317,7 @@ struct TransposeF16Table {
     int cout[kMaxConvs], k[kMaxConvs], cin[kMaxConvs];
     unsigned w[kMaxConvs];        // fp32 weights in the parameter arena (floats)
     unsigned wT[kMaxConvs];       // 16-bit elements into the transposed-weight arena
+    int tile_begin[kMaxConvs + 1];   // prefix sums of K*K*(Cout/32)*(Cin/32) 32x32 tiles
 };
 int launch_transpose_flip_f16_all(const TransposeF16Table& t, const float* params, void* wT16,
                                   int bf16, hipStream_t s);

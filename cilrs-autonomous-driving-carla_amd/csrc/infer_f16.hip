@@ -262,6 +262,15 @@ __global__ __launch_bounds__(256, (BM == 64 ? 2 : 2)) void conv_f16_kernel(const
         __syncthreads();
         constexpr int TPR = BN / 8, RPP = 256 / TPR;
         const int c8 = (tid % TPR) * 8, rsub = tid / TPR;
+        const bool bwd = a.bwd_partial != nullptr;
+        f32x4 mlo = {0.f, 0.f, 0.f, 0.f}, mhi = mlo, rlo = mlo, rhi = mlo;
+        f32x4 s1lo = mlo, s1hi = mlo, s2lo = mlo, s2hi = mlo;
+        if (bwd) {
+            mlo = *reinterpret_cast<const f32x4*>(a.bwd_stats + n0 + c8);
+            mhi = *reinterpret_cast<const f32x4*>(a.bwd_stats + n0 + c8 + 4);
+            rlo = *reinterpret_cast<const f32x4*>(a.bwd_stats + a.Cout + n0 + c8);
+            rhi = *reinterpret_cast<const f32x4*>(a.bwd_stats + a.Cout + n0 + c8 + 4);
+        }
 #pragma unroll
         for (int pass = 0; pass < BM / RPP; ++pass) {
             const int row = pass * RPP + rsub;
@@ -276,6 +285,44 @@ __global__ __launch_bounds__(256, (BM == 64 ? 2 : 2)) void conv_f16_kernel(const
             }
             *reinterpret_cast<f32x4*>(a.y32 + o) = lo;
             *reinterpret_cast<f32x4*>(a.y32 + o + 4) = hi;
+            if (bwd) {
+                const f32x4 ylo = *reinterpret_cast<const f32x4*>(a.bwd_y + o);
+                const f32x4 yhi = *reinterpret_cast<const f32x4*>(a.bwd_y + o + 4);
+                f32x4 glo = lo, ghi = hi;
+                if (a.bwd_relu) {
+                    const f32x4 zlo = *reinterpret_cast<const f32x4*>(a.bwd_z + o);
+                    const f32x4 zhi = *reinterpret_cast<const f32x4*>(a.bwd_z + o + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        glo[e] = zlo[e] > 0.f ? glo[e] : 0.f;
+                        ghi[e] = zhi[e] > 0.f ? ghi[e] : 0.f;
+                    }
+                }
+                s1lo += glo; s1hi += ghi;
+                s2lo += glo * ((ylo - mlo) * rlo);
+                s2hi += ghi * ((yhi - mhi) * rhi);
+            }
+        }
+        if (bwd) {
+            // column sums over the tile's rows: [RPP row-threads][BN] through LDS, fixed order
+            float* red1 = stage + BM * SP;                       // [RPP][BN]
+            float* red2 = red1 + RPP * BN;
+            *reinterpret_cast<f32x4*>(&red1[rsub * BN + c8]) = s1lo;
+            *reinterpret_cast<f32x4*>(&red1[rsub * BN + c8 + 4]) = s1hi;
+            *reinterpret_cast<f32x4*>(&red2[rsub * BN + c8]) = s2lo;
+            *reinterpret_cast<f32x4*>(&red2[rsub * BN + c8 + 4]) = s2hi;
+            __syncthreads();
+            if (tid < BN) {
+                float t1 = 0.f, t2 = 0.f;
+#pragma unroll 8
+                for (int r = 0; r < RPP; ++r) {
+                    t1 += red1[r * BN + tid];
+                    t2 += red2[r * BN + tid];
+                }
+                const size_t mt = (size_t)(logical / tilesN), nmt = (size_t)((M + BM - 1) / BM);
+                a.bwd_partial[(size_t)(n0 + tid) * nmt + mt] = t1;
+                a.bwd_partial[(size_t)(a.Cout + n0 + tid) * nmt + mt] = t2;
+            }
         }
         return;
     }
@@ -434,6 +481,8 @@ int launch_conv_f16_train(const ConvF16Args& a, hipStream_t s) {
                 "conv_f16_train: fp32 output missing / misaligned");
     CILRS_CHECK((size_t)a.N * a.H * a.W * a.Cin * 2 < (1ull << 32), "conv_f16_train: input too large");
     CILRS_CHECK(!a.up2 || a.stride == 2, "conv_f16_train: up2 is the stride-2 data gradient");
+    CILRS_CHECK(!a.bwd_partial || (a.bwd_y && a.bwd_stats && (a.bwd_z || !a.bwd_relu) && !a.up2),
+                "conv_f16_train: BatchNorm-backward partials need y / stats (/ z), stride 1");
     const int M = a.N * a.Ho * a.Wo;
     return a.bf16 ? launch_conv_f16_train_t<__bf16>(a, M, s)
                   : launch_conv_f16_train_t<_Float16>(a, M, s);
@@ -470,35 +519,45 @@ int launch_transpose_flip_f16(const float* w, void* wT, int Cout, int K, int Cin
     return 0;
 }
 
-// every convolution's transposed, tap-flipped 16-bit weights in one launch (blockIdx.y = conv)
+// every convolution's transposed, tap-flipped 16-bit weights in one launch.  Per filter tap this is
+// a [Cout][Cin] -> [Cin][Cout] transpose: 32x32 tiles through LDS, so the fp32 reads run along Cin
+// (128-byte rows) and the 16-bit writes along Cout (64-byte rows).  blockIdx.x walks the tiles of
+// all convolutions (tile_begin = prefix sums; Cout and Cin are multiples of 32 here).
 template <typename T>
 __global__ __launch_bounds__(256) void transpose_flip_all_kernel(const TransposeF16Table t,
                                                                  const float* __restrict__ params,
                                                                  T* __restrict__ wT16) {
-    const int l = blockIdx.y;
+    __shared__ float tile[32][33];
+    int l = 0;
+    while (l + 1 < t.n && (int)blockIdx.x >= t.tile_begin[l + 1]) ++l;
+    int b = (int)blockIdx.x - t.tile_begin[l];
     const int Cout = t.cout[l], K = t.k[l], Cin = t.cin[l];
+    const int tci = Cin / 32, tco = Cout / 32;
+    const int ci0 = (b % tci) * 32; b /= tci;
+    const int co0 = (b % tco) * 32;
+    const int tp = b / tco;                                  // flipped tap index (kh', kw')
+    const int kh = K - 1 - tp / K, kw = K - 1 - tp % K;
     const float* w = params + t.w[l];
     T* wT = wT16 + t.wT[l];
-    const size_t total = (size_t)Cin * K * K * Cout;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (size_t)gridDim.x * blockDim.x) {
-        const int co = (int)(i % Cout);
-        size_t r = i / Cout;
-        const int tp = (int)(r % (K * K));
-        const int ci = (int)(r / (K * K));
-        const int kh = K - 1 - tp / K, kw = K - 1 - tp % K;
-        wT[i] = (T)w[(((size_t)co * K + kh) * K + kw) * Cin + ci];
-    }
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+    for (int r = ty; r < 32; r += 8)
+        tile[r][tx] = w[(((size_t)(co0 + r) * K + kh) * K + kw) * Cin + ci0 + tx];
+    __syncthreads();
+#pragma unroll
+    for (int r = ty; r < 32; r += 8)
+        wT[((size_t)(ci0 + r) * K * K + tp) * Cout + co0 + tx] = (T)tile[tx][r];
 }
 
 int launch_transpose_flip_f16_all(const TransposeF16Table& t, const float* params, void* wT16,
                                   int bf16, hipStream_t s) {
     if (t.n <= 0) return 0;
+    const int total = t.tile_begin[t.n];
     if (bf16)
-        transpose_flip_all_kernel<__bf16><<<dim3(64, t.n), 256, 0, s>>>(
-            t, params, reinterpret_cast<__bf16*>(wT16));
+        transpose_flip_all_kernel<__bf16><<<total, 256, 0, s>>>(t, params,
+                                                               reinterpret_cast<__bf16*>(wT16));
     else
-        transpose_flip_all_kernel<_Float16><<<dim3(64, t.n), 256, 0, s>>>(
+        transpose_flip_all_kernel<_Float16><<<total, 256, 0, s>>>(
             t, params, reinterpret_cast<_Float16*>(wT16));
     CILRS_LAUNCH_CHECK();
     return 0;

@@ -502,9 +502,16 @@ int conv_fwd16(cilrs_net* net, const ConvT& c, const ConvG& g, int ci, const cil
 }
 
 int conv_dgrad16(cilrs_net* net, const ConvT& c, const ConvG& g, int ci, const cilrs_half* dy16,
-                 float* dx, const float* addend, float* ws, hipStream_t s) {
+                 float* dx, const float* addend, float* ws, hipStream_t s,
+                 const ConvG* bn_of = nullptr, int* bwd_nblk = nullptr) {
     ConvF16Args a;
     memset(&a, 0, sizeof(a));
+    if (bwd_nblk) *bwd_nblk = 0;
+    if (bn_of && bwd_nblk && c.stride == 1) {     // the BatchNorm whose output gradient this is
+        a.bwd_z = ws + bn_of->z; a.bwd_y = ws + bn_of->y; a.bwd_stats = ws + bn_of->stats;
+        a.bwd_relu = 1; a.bwd_partial = ws + net->bn_partial;
+        *bwd_nblk = cdiv(net->B * g.H * g.W, 64);
+    }
     a.x = dy16; a.w = h16(ws, net->wT16) + net->wT16_off[ci]; a.y32 = dx; a.addend32 = addend;
     a.N = net->B; a.H = g.Ho; a.W = g.Wo; a.Cin = c.cout;      // gathered tensor = dy
     a.Ho = g.H; a.Wo = g.W; a.Cout = c.cin;                    // enumerated grid = dx
@@ -828,6 +835,9 @@ int cilrs_net_create_ex(int variant, int batch, int height, int width, unsigned 
             n->tr_table.cout[e] = c.cout; n->tr_table.k[e] = c.k; n->tr_table.cin[e] = c.cin;
             n->tr_table.w[e] = (unsigned)c.w;
             n->tr_table.wT[e] = (unsigned)halfs;
+            n->tr_table.tile_begin[e] = e == 0 ? 0 : n->tr_table.tile_begin[e];
+            n->tr_table.tile_begin[e + 1] =
+                n->tr_table.tile_begin[e] + c.k * c.k * (c.cout / 32) * (c.cin / 32);
             n->wT16_off[ci] = halfs;
             halfs += ((size_t)c.cout * c.k * c.k * c.cin + 7) / 8 * 8;
             n->z16[ci] = bump.take(((size_t)n->cg[ci].M * c.cout + 1) / 2);
@@ -1448,10 +1458,9 @@ int cilrs_net_backward(cilrs_net* net, const cilrs_buffers* bufs, const float* d
                                  const ConvG* bn_of, int* nbp) -> int {
                     const ConvT& c = A.convs[ci];
                     const ConvG& g = net->cg[ci];
-                    if (bf16t) {
-                        if (nbp) *nbp = 0;       // BatchNorm reduces its own columns in this mode
-                        return conv_dgrad16(net, c, g, ci, h16(ws, net->G16[gi]), dx, addend, ws, s);
-                    }
+                    if (bf16t)
+                        return conv_dgrad16(net, c, g, ci, h16(ws, net->G16[gi]), dx, addend, ws, s,
+                                            bn_of, nbp);
                     return conv_dgrad(net, c, g, ws + net->G[gi], P + c.w, dx, addend, ws, s, bn_of,
                                       1, nbp);
                 };
