@@ -1250,3 +1250,25 @@ def test_bf16_training_mode_vs_its_emulation(net, B, H, W, cfg_name):
     with torch.no_grad():
         c_eval, _ = m(*to_dev(imgs, spds, cmds))
     assert torch.isfinite(c_eval).all()
+
+
+def test_bf16_training_mode_learns_like_fp32():
+    """Thirty Adam steps on one batch from the same initial weights: the bf16 matrix-pipe mode
+    drives the loss down like the fp32 mode (same engine, same kernels around the convolutions)."""
+    from cilrs_mi355 import CILRS, CONFIG_A, Trainer
+    imgs, spds, cmds, tgts = to_dev(*O.synthetic_batch(16, seed=5)[:4])
+    hist = {}
+    for prec in ("fp32", "bf16"):
+        m = CILRS(4, 0.0)
+        m.load_state_dict(O.portable_state_dict(m.state_dict(), 0), strict=True)
+        tr = Trainer(m.cuda(), CONFIG_A, precision=prec)
+        ls = []
+        for _ in range(30):
+            tr.train_step(imgs, spds, cmds, tgts)
+            ls.append(tr.losses()["total"])
+        hist[prec] = ls
+    f, b = hist["fp32"], hist["bf16"]
+    print("fp32", [round(x, 4) for x in f[::5]], "bf16", [round(x, 4) for x in b[::5]])
+    assert abs(b[0] - f[0]) <= 2e-2 * f[0]                 # first step: same weights, bf16 accuracy
+    assert f[-1] < 0.25 * f[0] and b[-1] < 0.25 * b[0]     # both learn
+    assert b[-1] <= 2.0 * f[-1] + 1e-3                     # and end up in the same place
