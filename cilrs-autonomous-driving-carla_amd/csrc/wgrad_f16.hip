@@ -15,6 +15,8 @@
 // kernel (deterministic, no atomics).
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace cilrs {
 namespace {
 
@@ -185,7 +187,12 @@ W16Plan wplan16(const WgradF16Args& a) {
     const int Mpix = a.N * a.Ho * a.Wo;
     const int nsteps = cdiv(Mpix, WPIX);
     const int tiles = a.K * a.K * (a.Cin / 64) * (a.Cout / 64);
-    int splits = cdiv(1536, tiles);                 // ~6 blocks per CU in flight / queued
+    // blocks aimed at per launch (CILRS_W16_TARGET).  Measured with tools/bf16_train_probe.py, whole
+    // weight-gradient time per step, ResNet-50 variant B=64 176x400 / ResNet-34 B=128: target 256:
+    // 5.41 / 2.54 ms, 512: 3.67 / 1.84, 768: 3.63 / 2.00, 1536: 3.78 / 2.9, 3072: 4.32 / -- (the
+    // slabs are fp32: every extra split writes and re-reads a whole copy of the gradient)
+    static const int target = getenv("CILRS_W16_TARGET") ? atoi(getenv("CILRS_W16_TARGET")) : 512;
+    int splits = cdiv(target, tiles);
     const int max_splits = nsteps / 4 > 0 ? nsteps / 4 : 1;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
