@@ -526,6 +526,8 @@ CONV16_CASES = [  # N, H, W, Cin, Cout, K, stride, pad
     (2, 11, 13, 64, 256, 1, 2, 0),      # 1x1 stride-2 down-sample branch, odd size
     (1, 6, 13, 256, 256, 3, 1, 1),
     (5, 7, 7, 64, 64, 3, 2, 1),         # odd size, stride 2
+    (2, 12, 10, 128, 128, 3, 2, 1),     # 128-wide weight-gradient tile, stride 2
+    (3, 5, 9, 256, 128, 1, 1, 0),       # 128-wide tile, 1x1, ragged pixel count
 ]
 
 
