@@ -570,9 +570,9 @@ def main():
         # ... and on the bf16 matrix pipe (Trainer(precision="bf16"): trunk convolutions of the
         # step multiply bf16 operands, fp32 accumulation; BatchNorm / heads / Adam / master
         # weights fp32) -- BASELINE configs[3] as stated, one GPU's share
-        def bf16_leg(model, batch_t, tag, steps=5):
+        def bf16_leg(model, batch_t, tag, steps=10):
             trb = Trainer(model, _CA, precision="bf16")
-            for _ in range(2):
+            for _ in range(4):
                 trb.train_step(*batch_t)
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
