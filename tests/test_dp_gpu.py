@@ -139,7 +139,7 @@ def test_two_rank_train_step_matches_oracle_dp_semantics(tmp_path, cfg_name, var
         err = (sd0[n] - p.detach()).abs()
         assert float(err.max()) <= 2.2 * lr * 2 + 1e-6, n       # Adam's lr*sign(g) ambiguity
         # two free-running steps in: the measured drift gate of tests/test_model_gpu.py
-        # (OUTLIER_FRAC[2], tools/param_outliers.py) -- the gradient itself is pinned above
+        # (OUTLIER_FRAC[2], tests/calibrate_param_outliers.py) -- the gradient itself is pinned above
         assert int((err > 2e-5).sum()) <= max(64, int(0.25 * err.numel())), n
     # rank 1's BN statistics followed ITS shard
     want_rm1 = reps[1].state_dict()["visual_encoder.1.running_mean"]

@@ -14,7 +14,7 @@ Tolerances (BASELINE.json north_star: "within 1e-4 fp32 on identical batches"):
   params after k Adam steps   Adam moves an element whose gradient is within fp32 noise of zero
                   by +-lr per step whatever the implementation, so: hard bound 2.2*lr*k on every
                   element, and the FRACTION of elements beyond 2e-5 gated at ~10x what
-                  tools/param_outliers.py measures on MI355X (see _close_params); the optimiser's
+                  tests/calibrate_param_outliers.py measures on MI355X (see _close_params); the optimiser's
                   own arithmetic is pinned element-wise at 1e-6 over five steps by
                   tests/test_ops_gpu.py::test_adam_step_matches_torch_adam
   B = 128         one whole fused train step per config against the oracle at the benchmark
@@ -124,7 +124,7 @@ def _fp64_grads(ocfg, imgs, spds, cmds, tgts, build=None):
 
 # Fraction of a tensor's elements allowed to differ by more than 2e-5 after k Adam steps, and the
 # count allowed in tensors too small for a fraction to mean anything.  Measured on MI355X with
-# tools/param_outliers.py (profiles/r02_param_outliers.log): see OUTLIER_FRAC below.
+# tests/calibrate_param_outliers.py (profiles/r02_param_outliers.log): see OUTLIER_FRAC below.
 #   one step from identical state (Adam's step-1 update is lr*sign(g), so only sign flips of
 #   near-zero gradients show): 2.5e-6 (B=4) ... 2.8e-3 (B=5, 64x64 frames) of all elements,
 #   1.1e-3 at B=128; worst tensor 6.3e-3; at most 4 elements in any tensor below 4096 elements
