@@ -222,6 +222,10 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world > 1:
+        # N ranks share the node's CPUs: keep every rank's host thread pool to its share
+        from cilrs_mi355 import hostinfo as _hi
+        torch.set_num_threads(max(1, _hi.usable_cores() // world))
     if args.rehearse:
         return rehearse(args, rank, world, real_stdout)
     if not torch.cuda.is_available():
