@@ -465,6 +465,17 @@ def main():
                         "lanes_graph_frames_per_s": round(320 / t_graph, 1),
                         "sequential_frames_per_s": round(320 / t_seq, 1),
                         "sequential_ms_per_batch": round(t_seq / 5 * 1e3, 3)}
+            # the same 320 frames as ONE batch (what a batching server would submit)
+            u320 = u64.view(320, 88, 200, 3)
+            s320, c320 = spd64.repeat(5), cmd64.repeat(5)
+            for _ in range(2):
+                eng.run_forward_u8(u320, s320, c320, half=half)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(5):
+                eng.run_forward_u8(u320, s320, c320, half=half)
+            torch.cuda.synchronize(dev)
+            out[key]["one_batch_of_320_frames_per_s"] = round(320 * 5 / (time.perf_counter() - t0), 1)
         # device-side breakdown of one B=1 forward (eager launches, hipEvent per kernel)
         pl1 = trainer.eng.plan(1, 88, 200)
         pl1.profile_reset()
