@@ -337,6 +337,15 @@ int launch_f32_to_f16(const float* x, void* y, size_t n, int bf16, hipStream_t s
 int launch_avgpool_f16(const void* x, float* out, int N, int HW, int C, int out_ld, int bf16,
                        hipStream_t s);
 
+// 16-bit stem of the serving path (stem_f16.hip): conv 7x7/s2 + folded BN + ReLU on the channel-
+// padded fp32 image -> 16-bit [N][Ho][Wo][64]; max-pool 3x3/s2/p1 on 16-bit NHWC
+int launch_fold_stem_f16(const float* w, const float* stats, void* w16, float* bias, int bf16,
+                         hipStream_t s);
+int launch_stem_f16(const float* x4, const void* w16, const float* bias, void* z, int N, int H,
+                    int W, int bf16, hipStream_t s);
+int launch_maxpool_f16(const void* x, void* out, int N, int H, int W, int C, int bf16,
+                       hipStream_t s);
+
 // 16-bit weight gradient (wgrad_f16.hip): dw fp32 OHWI from 16-bit NHWC x and dy
 struct WgradF16Args {
     const void* x;         // [N][H][W][Cin] 16-bit

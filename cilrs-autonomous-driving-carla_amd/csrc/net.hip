@@ -281,6 +281,7 @@ struct cilrs_net {
     BnEvalTable bn_table;
     FoldF16Table f16_table;                // fp16 inference: folded weights / biases / activations
     size_t f16_w, f16_bias, f16_act[5], f16_act_floats;
+    size_t stem16_w = 0, stem16_b = 0;     // folded 16-bit stem weights [64][7][8][4] / fp32 shift
     // cached hipGraph of the uint8 inference path (fixed pointers)
     hipGraphExec_t graph_exec = nullptr;
     int graph_half = 0;
@@ -821,6 +822,8 @@ int cilrs_net_create_ex(int variant, int batch, int height, int width, unsigned 
         }
         n->f16_w = bump.take((halfs + 1) / 2);
         n->f16_bias = bump.take(floats);
+        n->stem16_w = bump.take(64 * 224 / 2);
+        n->stem16_b = bump.take(64);
         n->f16_act_floats = (actmax + 1) / 2;                              // largest trunk tensor
         for (int k = 0; k < 5; ++k) n->f16_act[k] = bump.take(n->f16_act_floats);
     }
@@ -1014,11 +1017,13 @@ static int forward_from_x4(cilrs_net* net, const cilrs_buffers* bufs, const floa
             net->prep_bufs[2] = bufs->workspace;
             net->fold_key = 0;
         }
-        if (conv_fwd(net, A.convs[0], net->cg[0], ws + net->x4, 4, ws + net->w4,
-                     ws + net->cg[0].z, ws, s, nullptr, ws + net->cg[0].stats, 1)) return 1;
-        RUN(net, "maxpool", 0.0, 4.0 * net->cg[0].M * 64 * 1.25, s,
-            launch_maxpool_fwd(ws + net->cg[0].z, ws + net->pool, nullptr, B, net->H0, net->W0,
-                               64, s));
+        if (!half) {
+            if (conv_fwd(net, A.convs[0], net->cg[0], ws + net->x4, 4, ws + net->w4,
+                         ws + net->cg[0].z, ws, s, nullptr, ws + net->cg[0].stats, 1)) return 1;
+            RUN(net, "maxpool", 0.0, 4.0 * net->cg[0].M * 64 * 1.25, s,
+                launch_maxpool_fwd(ws + net->cg[0].z, ws + net->pool, nullptr, B, net->H0,
+                                   net->W0, 64, s));
+        }
         cur = ws + net->pool;
         if (half) {
             // ---- fp16 trunk (BASELINE config 5): BatchNorm folded into fp16 weights, fp16 NHWC
@@ -1033,12 +1038,24 @@ static int forward_from_x4(cilrs_net* net, const cilrs_buffers* bufs, const floa
             if (!fold_cached) {
                 RUN(net, "transform", 0.0, 0.0, s,
                     launch_fold_bn_f16(net->f16_table, P, ws, w16, b16, bf16, s));
+                RUN(net, "transform", 0.0, 0.0, s,
+                    launch_fold_stem_f16(P + A.convs[0].w, ws + net->cg[0].stats,
+                                         h16(ws, net->stem16_w), ws + net->stem16_b, bf16, s));
                 net->fold_key = net->weights_key;
                 net->fold_half = half;
             }
-            RUN(net, "transform", 0.0, 0.0, s,
-                launch_f32_to_f16(ws + net->pool, act[0], (size_t)B * net->H1 * net->W1 * 64, bf16,
-                                  s));
+            // stem on the 16-bit pipe too (stem_f16.hip): conv 7x7/s2 + folded BN + ReLU from the
+            // channel-padded fp32 image, 16-bit output parked in the (otherwise unused) fp32 stem
+            // buffer, then the 16-bit max-pool straight into the first activation buffer
+            {
+                const ConvG& g0 = net->cg[0];
+                RUN(net, "conv_fwd.stem", 2.0 * g0.M * 64 * 147, 16.0 * B * net->H * net->W +
+                    2.0 * g0.M * 64, s,
+                    launch_stem_f16(ws + net->x4, h16(ws, net->stem16_w), ws + net->stem16_b,
+                                    h16(ws, g0.z), B, net->H, net->W, bf16, s));
+                RUN(net, "maxpool", 0.0, 2.0 * g0.M * 64 * 1.25, s,
+                    launch_maxpool_f16(h16(ws, g0.z), act[0], B, net->H0, net->W0, 64, bf16, s));
+            }
             int ic = 0;                                  // index of the buffer holding `cur`
             auto conv16 = [&](int ci, const cilrs_half* x, const cilrs_half* residual,
                               cilrs_half* y, int relu) -> int {

@@ -9,6 +9,6 @@ for m in "$@"; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -Wno-unused-variable -Wno-unused-but-set-variable \
       -DCILRS_IGEMM_DBG=$m -c conv_igemm.hip -o /tmp/conv_igemm_dbg$m.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../cilrs_mi355/libcilrs_hip_dbg$m.so \
-      /tmp/conv_igemm_dbg$m.o conv_wgrad.o bn_pool.o heads_optim.o heads_gemm.o augment.o infer_f16.o wgrad_f16.o conv_small.o net.o
+      /tmp/conv_igemm_dbg$m.o conv_wgrad.o bn_pool.o heads_optim.o heads_gemm.o augment.o infer_f16.o wgrad_f16.o stem_f16.o conv_small.o net.o
   echo built libcilrs_hip_dbg$m.so
 done
