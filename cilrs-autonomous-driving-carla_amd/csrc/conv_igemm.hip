@@ -62,7 +62,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // instead of 1,024 -- layer2's 1,100 tiles then fit in one round.
 // Timing experiments only (tools/igemm_dbg.sh builds side libraries with -DCILRS_IGEMM_DBG=mask; results
 // are numerically meaningless): 1 = no global loads in the K loop, 2 = no LDS stores, 4 = no
-// barriers, 8 = no LDS reads (operands stay in registers)
+// barriers, 8 = no LDS reads (operands stay in registers), 16 = ADD the work of a BatchNorm apply
+// fused into the A-operand path (two 16-byte table loads, scale/shift, ReLU, padding mask per
+// element between the global load and the LDS store): what VERDICT-style "apply folded into the
+// next convolution's operand load" would cost this K loop
 #ifndef CILRS_IGEMM_DBG
 #define CILRS_IGEMM_DBG 0
 #endif
@@ -289,10 +292,30 @@ void conv_igemm_kernel(const ConvArgs a, const int M_, const int Krow, const int
         if (++ld_c == cin_tiles) { ld_c = 0; ++ld_tap; }
     };
 
-    auto store_tile = [&](int buf, const f32x4(&ra)[A_PASSES], const f32x4(&rb)[B_PASSES]) {
+    int st_tap = kt_begin / cin_tiles, st_c = kt_begin - (kt_begin / cin_tiles) * cin_tiles;
+    auto store_tile = [&](int buf, const f32x4(&ra_in)[A_PASSES], const f32x4(&rb)[B_PASSES]) {
         if constexpr (CILRS_IGEMM_DBG & 2) {
-            asm volatile("" ::"v"(ra[0]), "v"(rb[0]), "v"(ra[A_PASSES - 1]), "v"(rb[B_PASSES - 1]));
+            asm volatile("" ::"v"(ra_in[0]), "v"(rb[0]), "v"(ra_in[A_PASSES - 1]), "v"(rb[B_PASSES - 1]));
             return;
+        }
+        f32x4 ra[A_PASSES];
+#pragma unroll
+        for (int i = 0; i < A_PASSES; ++i) ra[i] = ra_in[i];
+        if constexpr ((CILRS_IGEMM_DBG & 16) && TAP_UNIFORM) {
+            const int ch = (st_c * BK + kq * 4) & 1023;          // stand-in scale / shift tables
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(a.w + ch);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(a.w + 1024 + ch);
+            const unsigned bit = 1u << st_tap;
+#pragma unroll
+            for (int i = 0; i < A_PASSES; ++i) {
+                const bool in_image = (rowMask[i] & bit) != 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = fmaxf(fmaf(ra[i][e], sc[e], sh[e]), 0.f);
+                    ra[i][e] = in_image ? v : 0.f;
+                }
+            }
+            if (++st_c == cin_tiles) { st_c = 0; ++st_tap; }
         }
         float* Ab = As + buf * BM * APIT;
         float* Bb = Bs + buf * B_FLOATS;

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Side builds of the library with pieces of the implicit-GEMM K loop removed (timing experiments;
 # results are numerically meaningless): libcilrs_hip_dbg<mask>.so next to the real one.
-# mask bits: 1 no global loads, 2 no LDS stores, 4 no barriers, 8 no LDS reads.
+# mask bits: 1 no global loads, 2 no LDS stores, 4 no barriers, 8 no LDS reads, 16 ADD a fused BatchNorm-apply to the A operand.
 set -e
 cd "$(dirname "$0")/../cilrs-autonomous-driving-carla_amd/csrc"
 make -s
