@@ -1293,3 +1293,30 @@ def test_bf16_training_mode_other_geometries(B, H, W):
         assert abs(got[k] - v) <= 3e-2 * max(1.0, abs(v)), (k, got[k], v)
     tr.train_step(*to_dev(imgs, spds, cmds, tgts))
     assert tr.losses()["total"] < got["total"]
+
+
+def test_bf16_training_mode_is_bit_reproducible():
+    """No atomics anywhere in the 16-bit kernels either (K-slabs summed in slab order, BatchNorm
+    partials in tile order): the same step from the same state gives bit-identical gradients and
+    parameters, and the backward pass is exactly linear in the output gradient."""
+    from cilrs_mi355 import CILRS, CONFIG_A, Trainer
+    imgs, spds, cmds, tgts = to_dev(*O.synthetic_batch(24, seed=3)[:4])
+    outs = []
+    for _ in range(2):
+        m = CILRS(4, 0.0)
+        m.load_state_dict(O.portable_state_dict(m.state_dict(), 0), strict=True)
+        tr = Trainer(m.cuda(), CONFIG_A, precision="bf16")
+        tr.train_step(imgs, spds, cmds, tgts)
+        g = tr.eng.grads.clone()
+        tr.train_step(imgs, spds, cmds, tgts)
+        outs.append((g, tr.eng.params.clone(), tr.losses()["total"]))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert outs[0][2] == outs[1][2]
+    eng = tr.eng
+    m.train()
+    controls, pred_speed, pl = eng.run_forward(imgs, spds, cmds, True, 0.0, 0)
+    _, dc, dp = tr.loss(controls, tgts, pred_speed, spds)
+    eng.run_backward(pl, dc, dp)
+    g1 = eng.grads.clone()
+    eng.run_backward(pl, 2.0 * dc, 2.0 * dp)
+    assert torch.equal(eng.grads, 2.0 * g1)     # x2 commutes with every rounding (fp32 and bf16)
