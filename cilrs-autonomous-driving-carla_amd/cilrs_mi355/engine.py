@@ -99,7 +99,11 @@ class Plan:
     def check_status(self):
         """Synchronising read of the status words of the last forward on this plan; raises what
         the reference's ``all_out.gather(0, idx)`` raises for an out-of-range command."""
-        if int(self.status[0]) != 0:
+        st = self.status.tolist()
+        if st[1] != 0:
+            raise RuntimeError("CILRS persistent forward: a grid barrier gave up (another "
+                               "persistent launch was holding the device); outputs are NaN")
+        if st[0] != 0:
             raise RuntimeError("CILRS.forward: command index out of range (expected 0..3); "
                                "torch.gather raises 'index out of bounds' here "
                                "(model/autonomous_drive.py:397-398)")
@@ -270,13 +274,15 @@ class Engine:
             self.last_plan.check_status()
 
     def run_forward_u8(self, frames_u8, speed, command, out=None, graph=False, half=False,
-                       lane=0):
+                       lane=0, persistent=False):
         """uint8 RGB HWC frames [B,H,W,3] -> eval forward with fused preprocessing.  With
         graph=True the launch sequence is replayed from a cached hipGraph (all tensors must keep
         their addresses; the current stream must not be the default stream).  half=True / "f16"
         runs the trunk in fp16, half="bf16" in bf16 (BatchNorm folded into 16-bit weights, fp32
         accumulation): batched serving.  Calls issued on different HIP streams at the same time
-        must use different `lane`s (one workspace each)."""
+        must use different `lane`s (one workspace each).  persistent=True (one frame, fp32, the
+        reference network): the whole forward is ONE launch whose workgroups stay resident and
+        meet at in-launch grid barriers (csrc/infer_b1.hip) -- the control-loop path."""
         if frames_u8.dtype != torch.uint8 or frames_u8.dim() != 4 or frames_u8.size(3) != 3:
             raise RuntimeError("frames must be uint8 [B,H,W,3]")
         b = frames_u8.size(0)
@@ -288,7 +294,11 @@ class Engine:
         else:
             controls, pred_speed = out
         lib = L.lib()
-        if half == "bf16":
+        if persistent:
+            if half or b != 1 or self.variant != 0:
+                raise RuntimeError("persistent=True serves one fp32 frame of the reference network")
+            fn = lib.cilrs_net_forward_u8_b1
+        elif half == "bf16":
             fn = lib.cilrs_net_forward_u8_bf16_graph if graph else lib.cilrs_net_forward_u8_bf16
         elif half:
             fn = lib.cilrs_net_forward_u8_f16_graph if graph else lib.cilrs_net_forward_u8_f16

@@ -281,6 +281,52 @@ int launch_conv_small(const ConvSmallArgs& a, hipStream_t s);
 constexpr int kSmallConvBlocks = 256;              // 16x16 tiles up to which it is used
 constexpr int kSmallConvK = 2304;                  // reduction length up to which it is used
 
+// ---- persistent single-frame inference kernel (infer_b1.hip) ---------------------------------
+// The whole eval forward of ONE frame (reference control loop, model/autonomous_drive.py:908-920)
+// as ONE launch: one 1,024-thread workgroup per CU walks a table of stages (preprocess, stem,
+// max-pool, 33 convolution stages, three head layers) separated by in-launch grid barriers.
+// All byte offsets are 32-bit: activations / folded BatchNorm tables / padded stem weights live in
+// the plan's workspace, every other weight in the parameter arena.
+struct B1Conv {
+    unsigned x_off, y_off, add_off, w_off, scale_off, shift_off;   // bytes (w: arena, or ws if w_in_ws)
+    int H, W, Cin, Ho, Wo, Cout, K, stride, pad;
+    int M, nmt, ntiles;      // output pixels, 16-row tiles, 16x16 output tiles (nmt * Cout/16)
+    int S, cshift;           // k-groups (16 reduction indices each) per tile; log2(Cin / 16)
+    int relu, relu_post, has_add, w_in_ws;
+};
+struct B1Head {              // one nn.Linear of the commanded branch (chain 0) + speed head (chain 1)
+    unsigned w_off[5], b_off[5];     // branch 0..3, then the speed-predictor layer (arena bytes)
+    unsigned x_off[2], y_off[2];     // workspace bytes: input rows / outputs of the two chains
+    int in[2], out[2], relu, first, last;
+    // first layer only: avg-pool source + speed encoder (autonomous_drive.py:369-374, 390-392)
+    unsigned feat_off; int featHW, featC;
+    unsigned se_w0, se_b0, se_w1, se_b1;
+};
+enum { B1_PRE = 0, B1_CONV = 1, B1_STEM = 2, B1_POOL = 3, B1_HEAD = 4 };
+struct B1Stage {
+    int type, wpt, nprob, total_tiles;     // conv stages: waves per tile, sub-problems, tiles
+    B1Conv c[2];
+    B1Head h;
+    unsigned src_off, dst_off; int pH, pW, pC, pHo, pWo;    // B1_PRE / B1_POOL geometry
+    int pad_[1];
+};
+constexpr int kB1MaxStages = 48;
+constexpr int kB1SyncInts = 9 * 32;        // 8 counter shards + the epoch base, one 128-B line each
+struct B1Launch {
+    const B1Stage* table; int nstages;     // device table
+    float* ws; size_t ws_bytes;
+    const float* params; size_t param_bytes;
+    const unsigned char* frame; const float* speed; const long long* cmd;
+    float* controls; float* pred_speed;
+    int* sync;                              // kB1SyncInts ints, zeroed once
+    int* status;                            // [0] bad command, [1] grid barrier gave up
+    long long* stamps;                      // optional [2][kB1MaxStages + 1]: block 0's 100 MHz clock at
+                                            // every stage start / work end (diagnostics; NULL = off)
+    float mean[3], stdv[3];
+};
+int infer_b1_grid(int* blocks);             // resident grid size (0: kernel cannot run here)
+int launch_infer_b1(const B1Launch& a, int blocks, hipStream_t s);
+
 // ---- fp16 inference trunk (infer_f16.hip) -------------------------------------------------------
 typedef _Float16 cilrs_half;
 struct ConvF16Args {

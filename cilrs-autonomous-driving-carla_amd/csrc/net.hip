@@ -307,6 +307,12 @@ struct cilrs_net {
     size_t w16_all = 0, wT16 = 0, pool16 = 0, slabs16 = 0, slabs16_floats = 0;
     size_t z16[kMaxConvs] = {}, wT16_off[kMaxConvs] = {}, G16[kNumG] = {};
     TransposeF16Table tr_table;
+    // persistent single-frame kernel (infer_b1.hip): stage table + barrier counters in the
+    // workspace (offsets in floats; 0 = this plan has none), uploaded once per workspace
+    size_t b1_table = 0, b1_sync = 0, b1_stamps = 0;
+    std::vector<B1Stage> b1_host;
+    int b1_blocks = -1;                    // resident grid (one workgroup per CU); -1 = not asked yet
+    const void* b1_ready_for = nullptr;
     Prof prof;
 };
 
@@ -853,6 +859,11 @@ int cilrs_net_create_ex(int variant, int batch, int height, int width, unsigned 
         n->slabs16_floats = sl;
         n->slabs16 = bump.take(sl > 0 ? sl : 4);
     }
+    if (batch == 1 && variant == 0) {
+        n->b1_table = bump.take(kB1MaxStages * sizeof(B1Stage) / sizeof(float));
+        n->b1_sync = bump.take(kB1SyncInts);
+        n->b1_stamps = bump.take(2 * 10 * (kB1MaxStages + 1));
+    }
     n->ws_bytes = bump.off * sizeof(float);
     *out = n;
     return 0;
@@ -1333,6 +1344,217 @@ int cilrs_net_forward_u8_bf16(cilrs_net* net, const cilrs_buffers* bufs, const u
         launch_u8hwc_to_nhwc4(frames, ws + net->x4, (size_t)net->B * net->H * net->W, mean, stdv,
                               s));
     return forward_from_x4(net, bufs, speed, command, 0, 0.f, 0, controls, pred_speed, s, 2);
+}
+
+// ------------------------------------------------------------------------------------------------
+// single-frame inference as ONE persistent launch (infer_b1.hip)
+// ------------------------------------------------------------------------------------------------
+// eval-mode weight-derived state (the same two kernels and cache keys as the eager eval path)
+static int eval_prep(cilrs_net* net, const cilrs_buffers* bufs, hipStream_t s) {
+    const Arch& A = *net->A;
+    float* ws = reinterpret_cast<float*>(bufs->workspace);
+    const bool same_bufs = net->prep_bufs[0] == (const void*)bufs->params &&
+                           net->prep_bufs[1] == (const void*)bufs->bn_running &&
+                           net->prep_bufs[2] == (const void*)bufs->workspace;
+    if (net->weights_key != 0 && same_bufs && net->prep_key == net->weights_key) return 0;
+    RUN(net, "transform", 0.0, 0.0, s,
+        launch_pad_cin3_to_4(bufs->params + A.convs[0].w, ws + net->w4, 64 * 49, s));
+    RUN(net, "bn_fwd.eval", 0.0, 0.0, s,
+        launch_bn_eval_stats_all(net->bn_table, bufs->params, bufs->bn_running, ws, 1e-5f, s));
+    net->prep_key = net->weights_key;
+    net->prep_bufs[0] = bufs->params; net->prep_bufs[1] = bufs->bn_running;
+    net->prep_bufs[2] = bufs->workspace;
+    net->fold_key = 0;
+    return 0;
+}
+
+// Stage table of the persistent kernel for this plan on a grid of `nblk` workgroups.
+static int b1_build(cilrs_net* net, int nblk) {
+    const Arch& A = *net->A;
+    std::vector<B1Stage>& T = net->b1_host;
+    T.clear();
+    auto fb = [](size_t floats) { return (unsigned)(floats * sizeof(float)); };
+    auto pick_wpt = [&](int total) {
+        for (int w : {16, 8, 4, 2})
+            if (total <= nblk * (16 / w)) return w;
+        return 2;
+    };
+    auto conv_desc = [&](int ci, size_t x, bool has_add, size_t add, int relu, int relu_post) {
+        const ConvT& c = A.convs[ci];
+        const ConvG& g = net->cg[ci];
+        B1Conv d;
+        memset(&d, 0, sizeof(d));
+        d.x_off = fb(x); d.y_off = fb(g.z); d.add_off = has_add ? fb(add) : 0u;
+        d.scale_off = fb(g.stats + 2 * (size_t)c.cout); d.shift_off = fb(g.stats + 3 * (size_t)c.cout);
+        d.H = g.H; d.W = g.W; d.Ho = g.Ho; d.Wo = g.Wo; d.Cout = c.cout; d.K = c.k;
+        d.stride = c.stride; d.pad = c.pad; d.M = g.M; d.nmt = cdiv(g.M, 16);
+        d.ntiles = d.nmt * (c.cout / 16);
+        d.relu = relu; d.relu_post = relu_post; d.has_add = has_add ? 1 : 0;
+        if (ci == 0) {      // stem: channel-padded image, padded weights in the workspace
+            d.Cin = 4; d.w_off = fb(net->w4); d.w_in_ws = 1; d.S = cdiv(c.k * c.k, 4); d.cshift = 0;
+        } else {
+            d.Cin = c.cin; d.w_off = fb(c.w); d.w_in_ws = 0;
+            const int cgn = c.cin / 16;
+            d.S = c.k * c.k * cgn;
+            while ((1 << d.cshift) < cgn) ++d.cshift;
+        }
+        return d;
+    };
+    auto check_conv = [&](int ci) -> bool {
+        const ConvT& c = A.convs[ci];
+        const int cgn = c.cin / 16;
+        return c.cin % 16 == 0 && c.cout % 16 == 0 && c.k * c.k <= 9 && (cgn & (cgn - 1)) == 0;
+    };
+    auto push_conv_stage = [&](int type, const B1Conv& c0, const B1Conv* c1) {
+        B1Stage st;
+        memset(&st, 0, sizeof(st));
+        st.type = type; st.nprob = c1 ? 2 : 1;
+        st.c[0] = c0;
+        if (c1) st.c[1] = *c1;
+        st.total_tiles = c0.ntiles + (c1 ? c1->ntiles : 0);
+        st.wpt = pick_wpt(st.total_tiles);
+        T.push_back(st);
+    };
+    {   // uint8 frame -> normalised NHWC4
+        B1Stage st;
+        memset(&st, 0, sizeof(st));
+        st.type = B1_PRE; st.pH = net->H; st.pW = net->W; st.dst_off = fb(net->x4);
+        T.push_back(st);
+    }
+    push_conv_stage(B1_STEM, conv_desc(0, net->x4, false, 0, 1, 0), nullptr);
+    {   // max-pool 3x3/s2/p1
+        B1Stage st;
+        memset(&st, 0, sizeof(st));
+        st.type = B1_POOL; st.src_off = fb(net->cg[0].z); st.dst_off = fb(net->pool);
+        st.pH = net->H0; st.pW = net->W0; st.pC = 64; st.pHo = net->H1; st.pWo = net->W1;
+        T.push_back(st);
+    }
+    size_t cur = net->pool;
+    for (const BlockT& blk : A.blocks) {
+        CILRS_CHECK(blk.conv3 < 0, "infer_b1: BasicBlock networks only");
+        CILRS_CHECK(check_conv(blk.conv1) && check_conv(blk.conv2) &&
+                        (blk.down < 0 || check_conv(blk.down)),
+                    "infer_b1: unsupported convolution shape");
+        const B1Conv c1 = conv_desc(blk.conv1, cur, false, 0, 1, 0);
+        size_t identity = cur;
+        if (blk.down >= 0) {
+            const B1Conv cd = conv_desc(blk.down, cur, false, 0, 0, 0);
+            push_conv_stage(B1_CONV, c1, &cd);
+            identity = net->cg[blk.down].z;
+        } else {
+            push_conv_stage(B1_CONV, c1, nullptr);
+        }
+        push_conv_stage(B1_CONV, conv_desc(blk.conv2, net->cg[blk.conv1].z, true, identity, 0, 1),
+                        nullptr);
+        cur = net->cg[blk.conv2].z;
+    }
+    // heads: commanded branch (chain 0) and speed predictor (chain 1), layer by layer
+    for (int layer = 0; layer < 3; ++layer) {
+        B1Stage st;
+        memset(&st, 0, sizeof(st));
+        st.type = B1_HEAD;
+        B1Head& h = st.h;
+        for (int k = 0; k < 4; ++k) {
+            h.w_off[k] = fb(A.br[k][layer].w);
+            h.b_off[k] = fb(A.br[k][layer].b);
+        }
+        const LinT& sp = layer == 0 ? A.sp0 : layer == 1 ? A.sp3 : A.sp5;
+        h.w_off[4] = fb(sp.w); h.b_off[4] = fb(sp.b);
+        h.in[0] = A.br[0][layer].in; h.in[1] = sp.in;
+        h.out[0] = A.br[0][layer].out; h.out[1] = sp.out;
+        h.relu = layer < 2; h.first = layer == 0; h.last = layer == 2;
+        h.x_off[0] = fb(layer == 1 ? net->h1[0] : net->h2[0]);
+        h.x_off[1] = fb(layer == 1 ? net->p1 : net->p2);
+        h.y_off[0] = fb(layer == 0 ? net->h1[0] : net->h2[0]);
+        h.y_off[1] = fb(layer == 0 ? net->p1 : net->p2);
+        if (layer == 0) {
+            h.feat_off = fb(cur); h.featHW = net->featHW; h.featC = A.feat;
+            h.se_w0 = fb(A.se0.w); h.se_b0 = fb(A.se0.b);
+            h.se_w1 = fb(A.se3.w); h.se_b1 = fb(A.se3.b);
+            CILRS_CHECK(A.feat == 512 && h.in[0] == 640 && h.in[1] == 512,
+                        "infer_b1: head geometry");
+        }
+        CILRS_CHECK(h.in[0] % 4 == 0 && h.in[1] % 4 == 0 && h.in[0] <= 768 && h.in[1] <= 768,
+                    "infer_b1: head width");
+        T.push_back(st);
+    }
+    CILRS_CHECK((int)T.size() <= kB1MaxStages, "infer_b1: %d stages", (int)T.size());
+    return 0;
+}
+
+int cilrs_net_forward_u8_b1(cilrs_net* net, const cilrs_buffers* bufs, const uint8_t* frame,
+                            const float* speed, const int64_t* command, float* controls,
+                            float* pred_speed, void* stream) {
+    if (check_bufs(net, bufs, false)) return 1;
+    CILRS_CHECK(frame && speed && command && controls && pred_speed, "forward_u8_b1: NULL tensor");
+    CILRS_CHECK(net->B == 1 && net->A->variant == 0 && net->b1_table != 0,
+                "forward_u8_b1: the persistent kernel serves the reference network at batch 1");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    float* ws = reinterpret_cast<float*>(bufs->workspace);
+    net->ws_base = ws;
+    if (net->b1_blocks < 0) {
+        int blocks = 0;
+        if (infer_b1_grid(&blocks)) return 1;
+        CILRS_CHECK(blocks >= 8, "forward_u8_b1: the device cannot keep the persistent grid resident");
+        if (b1_build(net, blocks)) return 1;
+        net->b1_blocks = blocks;
+    }
+    if (eval_prep(net, bufs, s)) return 1;
+    if (net->b1_ready_for != bufs->workspace) {
+        CILRS_HIP(hipMemsetAsync(ws + net->b1_sync, 0, kB1SyncInts * sizeof(int), s));
+        CILRS_HIP(hipMemsetAsync(reinterpret_cast<char*>(bufs->workspace) + net->status_b, 0, 16, s));
+        CILRS_HIP(hipMemcpyAsync(ws + net->b1_table, net->b1_host.data(),
+                                 net->b1_host.size() * sizeof(B1Stage), hipMemcpyHostToDevice, s));
+        net->b1_ready_for = bufs->workspace;
+    }
+    B1Launch a;
+    memset(&a, 0, sizeof(a));
+    a.table = reinterpret_cast<const B1Stage*>(ws + net->b1_table);
+    a.nstages = (int)net->b1_host.size();
+    a.ws = ws; a.ws_bytes = net->ws_bytes;
+    a.params = bufs->params; a.param_bytes = net->A->arena_floats * sizeof(float);
+    a.frame = frame; a.speed = speed; a.cmd = reinterpret_cast<const long long*>(command);
+    a.controls = controls; a.pred_speed = pred_speed;
+    a.sync = reinterpret_cast<int*>(ws + net->b1_sync);
+    a.status = reinterpret_cast<int*>(reinterpret_cast<char*>(bufs->workspace) + net->status_b);
+    // CILRS_B1_STAMPS=1: block 0 records its clock at every stage (cilrs_net_b1_stage_us)
+    static const int stamps_on = getenv("CILRS_B1_STAMPS") ? atoi(getenv("CILRS_B1_STAMPS")) : 0;
+    a.stamps = stamps_on ? reinterpret_cast<long long*>(ws + net->b1_stamps) : nullptr;
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    for (int i = 0; i < 3; ++i) { a.mean[i] = mean[i]; a.stdv[i] = stdv[i]; }
+    RUN(net, "infer_b1", 2.0 * 2.798e9 / 2.0, 0.0, s, launch_infer_b1(a, net->b1_blocks, s));
+    net->trained_fwd = false;
+    net->last_dropout = 0.f;
+    return 0;
+}
+
+int cilrs_net_b1_stage_us(cilrs_net* net, const cilrs_buffers* bufs, float* start_us,
+                          float* work_us, int cap) {
+    CILRS_CHECK(net && bufs && bufs->workspace && start_us && work_us, "b1_stage_us: NULL");
+    CILRS_CHECK(net->b1_table != 0 && net->b1_blocks > 0, "b1_stage_us: no persistent launch yet");
+    const int n = (int)net->b1_host.size();
+    CILRS_CHECK(cap >= n, "b1_stage_us: need room for %d stages", n);
+    std::vector<long long> h(10 * (kB1MaxStages + 1));
+    CILRS_HIP(hipMemcpy(h.data(), reinterpret_cast<float*>(bufs->workspace) + net->b1_stamps,
+                        h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) {          // 100 MHz clock
+        start_us[i] = (float)((h[i] - h[0]) * 0.01);
+        work_us[i] = (float)((h[kB1MaxStages + 1 + i] - h[i]) * 0.01);
+    }
+    if (getenv("CILRS_B1_FINE"))           // conv stages: block 0 / wave 0 inside the stage
+        for (int i = 0; i < n; ++i) {
+            const long long* f = &h[2 * (kB1MaxStages + 1) + 8 * i];
+            fprintf(stderr, "stage %2d fine:", i);
+            for (int k = 0; k < 8; ++k) fprintf(stderr, " %6.2f", (f[k] - h[i]) * 0.01);
+            fprintf(stderr, "\n");
+        }
+    return 0;
+}
+
+int cilrs_net_b1_stages(cilrs_net* net) {
+    if (!net || net->b1_table == 0) return 0;
+    if (net->b1_blocks < 0) return -1;             // not launched yet
+    return (int)net->b1_host.size();
 }
 
 // Same as cilrs_net_forward_u8, replayed from a cached hipGraph (one launch per frame instead of

@@ -180,6 +180,28 @@ int cilrs_net_forward_u8_graph(cilrs_net* net, const cilrs_buffers* bufs, const 
                                const float* speed, const int64_t* command, float* controls,
                                float* pred_speed, void* stream);
 
+/* cilrs_net_forward_u8 for ONE frame as ONE persistent launch (csrc/infer_b1.hip): the agent's
+ * per-tick call `controls, pred_speed = self.model(img_t, speed_t, cmd_t)` under model.eval() and
+ * torch.no_grad() (predict_controls, model/autonomous_drive.py:908-920).  One 1,024-thread
+ * workgroup per CU walks a stage table (preprocess, stem, max-pool, the 16 BasicBlocks, avg-pool,
+ * speed encoder, the COMMANDED branch and the speed head) separated by in-launch grid barriers;
+ * no hipGraph, no per-layer launches.  Plans of batch 1 of the reference network only.  The device
+ * must be able to keep one workgroup per CU resident: a second persistent launch running at the
+ * same time on the same device (another stream, another process) can stall both until the bounded
+ * barrier spin gives up -- then status word 1 is set and the outputs are NaN.  Status word 0 is
+ * written by every call (1: command outside 0..3, where the reference's torch.gather raises). */
+int cilrs_net_forward_u8_b1(cilrs_net* net, const cilrs_buffers* bufs, const uint8_t* frame,
+                            const float* speed, const int64_t* command, float* controls,
+                            float* pred_speed, void* stream);
+/* number of stages (= grid barriers + 1) of that launch; -1 before the first call, 0 if the plan
+ * has no persistent path */
+int cilrs_net_b1_stages(cilrs_net* net);
+/* diagnostics (library started with CILRS_B1_STAMPS=1): block 0's clock of the LAST persistent
+ * launch -- start_us[i] = when stage i began (relative to stage 0), work_us[i] = how long block 0
+ * worked in it before it entered the grid barrier.  Synchronous (one device->host copy). */
+int cilrs_net_b1_stage_us(cilrs_net* net, const cilrs_buffers* bufs, float* start_us,
+                          float* work_us, int cap);
+
 /* CILRSLoss.forward + its gradient (notebook/notebook.ipynb:514-527).
  * kind 1: w0*L1(steer)+w1*L1(throttle)+w2*L1(brake)+w3*MSE(speed)     (executed config B)
  * kind 0: MSE(controls[B,3]) + w3*MSE(speed)                            (documented config A)

@@ -1320,3 +1320,66 @@ def test_bf16_training_mode_is_bit_reproducible():
     g1 = eng.grads.clone()
     eng.run_backward(pl, 2.0 * dc, 2.0 * dp)
     assert torch.equal(eng.grads, 2.0 * g1)     # x2 commutes with every rounding (fp32 and bf16)
+
+
+def test_persistent_single_frame_kernel_vs_eager_and_oracle():
+    """The control-loop forward as ONE persistent launch (csrc/infer_b1.hip, C-ABI
+    cilrs_net_forward_u8_b1; reference: predict_controls, model/autonomous_drive.py:908-920).
+    Contract: every one of the four outputs within 1e-4 of the CPU oracle and within 2e-5 of the
+    per-layer launch path (same arithmetic, another summation order inside a 16x16 tile), for all
+    four commands; bit-identical on every repetition (grid barriers + sc1 hand-offs deliver the
+    same bytes every time); a command outside 0..3 sets the status word; weight updates are
+    followed."""
+    from cilrs_mi355 import CONFIG_A, Trainer
+    from cilrs_mi355.predict import Predictor
+    m = make_model()
+    orc = O.build_oracle(0).eval()
+    eager = Predictor(m, persistent=False)
+    pers = Predictor(m)
+    assert pers.persistent and not eager.persistent
+    frames = [np.floor(O._hash_u01(11 + i, 5, 88 * 200 * 3) * 256).astype(np.uint8).reshape(88, 200, 3)
+              for i in range(3)]
+    frames.append(np.zeros((88, 200, 3), np.uint8))
+    frames.append(np.full((88, 200, 3), 255, np.uint8))
+    first = {}
+    for fi, frame in enumerate(frames):
+        for cmd in range(4):
+            kmh = 7.0 + 21.0 * cmd + fi
+            got = pers.predict_controls(frame, kmh, cmd)
+            ref = eager.predict_controls(frame, kmh, cmd)
+            want = O.predict_controls(orc, frame, kmh, cmd)
+            for a, b, w, tol in zip(got, ref, want, (1.0, 1.0, 1.0, 90.0)):
+                assert abs(a - b) <= 2e-5 * tol, (fi, cmd, got, ref)
+                assert abs(a - w) <= 1e-4 * tol, (fi, cmd, got, want)
+            first[(fi, cmd)] = got
+    # the stage count the launch walked: preprocess, stem, pool, 2 per BasicBlock, 3 head layers
+    from cilrs_mi355 import _lib as L
+    pl = pers.eng.plan(1, 88, 200)
+    assert L.lib().cilrs_net_b1_stages(pl.handle) == 3 + 2 * 16 + 3
+    # 300 further ticks, inputs changing every call: each must reproduce its first answer exactly
+    for it in range(300):
+        fi, cmd = it % len(frames), (it // 2) % 4
+        assert pers.predict_controls(frames[fi], 7.0 + 21.0 * cmd + fi, cmd) == first[(fi, cmd)], it
+    # out-of-range command: status word 0, like the per-layer path
+    dev = pers.eng.device
+    fr = torch.from_numpy(frames[0])[None].to(dev)
+    spd = torch.tensor([0.3], device=dev)
+    for bad in (4, -1):
+        pers.eng.run_forward_u8(fr, spd, torch.tensor([bad], device=dev), persistent=True)
+        with pytest.raises(RuntimeError, match="out of range"):
+            pers.eng.check_status()
+    pers.eng.run_forward_u8(fr, spd, torch.tensor([2], device=dev), persistent=True)
+    pers.eng.check_status()
+    # weights move (one Adam step): both paths follow and still agree
+    img, s_, c_, t_, _ = O.synthetic_batch(4, seed=5)
+    Trainer(m, CONFIG_A).train_step(*to_dev(img, s_, c_, t_))
+    m.eval()
+    got = pers.predict_controls(frames[1], 40.0, 1)
+    ref = eager.predict_controls(frames[1], 40.0, 1)
+    assert got != first[(1, 1)]
+    for a, b, tol in zip(got, ref, (1.0, 1.0, 1.0, 90.0)):
+        assert abs(a - b) <= 2e-5 * tol, (got, ref)
+    # the persistent path refuses what it does not serve
+    with pytest.raises(RuntimeError):
+        pers.eng.run_forward_u8(torch.cat([fr, fr]), torch.tensor([0.3, 0.3], device=dev),
+                                torch.tensor([0, 1], device=dev), persistent=True)
