@@ -287,12 +287,21 @@ constexpr int kSmallConvK = 2304;                  // reduction length up to whi
 // max-pool, 33 convolution stages, three head layers) separated by in-launch grid barriers.
 // All byte offsets are 32-bit: activations / folded BatchNorm tables / padded stem weights live in
 // the plan's workspace, every other weight in the parameter arena.
-struct B1Conv {
-    unsigned x_off, y_off, add_off, w_off, scale_off, shift_off;   // bytes (w: arena, or ws if w_in_ws)
-    int H, W, Cin, Ho, Wo, Cout, K, stride, pad;
-    int M, nmt, ntiles;      // output pixels, 16-row tiles, 16x16 output tiles (nmt * Cout/16)
-    int S, cshift;           // k-groups (16 reduction indices each) per tile; log2(Cin / 16)
-    int relu, relu_post, has_add, w_in_ws;
+struct B1Conv {              // 32 ints, 16-byte aligned inside B1Stage (read as eight 128-bit words)
+    unsigned x_off, y_off, add_off, w_off;       // bytes (w: arena; the stem's padded copy: ws)
+    unsigned scale_off, shift_off;               // folded BatchNorm per output channel (ws bytes)
+    int H, W;
+    int Cin, Wo, Cout, K;                        // K = 3 (pad 1), 1 (pad 0) or 7 (stem, pad 3)
+    int stride, M, nmt, ntiles;                  // output pixels, 16-row tiles, 16x16 output tiles
+    int S, cshift, krow4, relu;                  // k-groups per tile; log2(Cin/16); K*K*Cin*4
+    int relu_post, has_add;
+    unsigned wo_magic, nmt_magic;                // x / Wo == (x * wo_magic) >> 20 on the ranges used
+    int ksplit, sper, per;                       // workgroups per tile (split of the reduction index),
+    unsigned ks_magic;                           //   k-groups per workgroup / per wave; x / ksplit magic
+    unsigned slab_off;                           // ksplit > 1: partial tiles [ksplit][nmt*16][Cout] (ws)
+    int ticket0, nunits, nt;                     // first ticket word; units = ntiles / nt * ksplit;
+                                                 // channel tiles per unit (1, or 2 sharing the
+                                                 // activation fragments; then ksplit == 1)
 };
 struct B1Head {              // one nn.Linear of the commanded branch (chain 0) + speed head (chain 1)
     unsigned w_off[5], b_off[5];     // branch 0..3, then the speed-predictor layer (arena bytes)
@@ -304,14 +313,17 @@ struct B1Head {              // one nn.Linear of the commanded branch (chain 0) 
 };
 enum { B1_PRE = 0, B1_CONV = 1, B1_STEM = 2, B1_POOL = 3, B1_HEAD = 4 };
 struct B1Stage {
-    int type, wpt, nprob, total_tiles;     // conv stages: waves per tile, sub-problems, tiles
+    int type, wpt, nunits0, total_units;   // conv stages: waves per unit (tile x k-slice), units of
+                                           // sub-problem 0, units of both
     B1Conv c[2];
     B1Head h;
     unsigned src_off, dst_off; int pH, pW, pC, pHo, pWo;    // B1_PRE / B1_POOL geometry
     int pad_[1];
 };
 constexpr int kB1MaxStages = 48;
-constexpr int kB1SyncInts = 9 * 32;        // 8 counter shards + the epoch base, one 128-B line each
+constexpr int kB1Tickets = 512;            // split-K arrival tickets (one per output tile of a stage)
+constexpr int kB1SyncInts = 9 * 32 + kB1Tickets;   // 8 counter shards + the epoch base (one 128-B
+                                                   // line each), then the tickets
 struct B1Launch {
     const B1Stage* table; int nstages;     // device table
     float* ws; size_t ws_bytes;

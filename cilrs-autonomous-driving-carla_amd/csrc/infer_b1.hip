@@ -24,10 +24,20 @@
 // the remaining barriers (so nobody else hangs on it), skips the work, and the outputs are NaN.
 //
 // Convolution stage = conv_small.hip's scheme inside the stage loop: a 16x16 output tile per
-// group of WPT waves (2..16, chosen per stage so that one pass of tile slots covers the layer), the
+// group of WPT waves (2..16, chosen per stage so that one pass of slots covers the layer), the
 // waves of a group split the reduction index, operands global -> registers ->
 // v_mfma_f32_16x16x4_f32, partial tiles summed through LDS in wave order (deterministic), folded
-// BatchNorm / ReLU / residual epilogue by the group's first wave.
+// BatchNorm / ReLU / residual epilogue by the group's first wave.  What bounds a stage is the
+// operand stream into each CU (measured ~70 GB/s per CU from L2: a 16x16 tile with reduction
+// length 2,304 is 288 KB = 4 us), so
+//   * layers whose tiles do not cover the CUs split the reduction index over SEVERAL workgroups
+//     (layer4: 64 tiles x 4): each parks its partial tile in a slab (sc1), takes a ticket, and the
+//     workgroup whose ticket is last sums the slabs in slice order (deterministic) and runs the
+//     epilogue;
+//   * everything of stage s+1 that does not depend on stage s -- descriptor, addresses, the
+//     WEIGHT fragments, folded BatchNorm -- is computed / loaded BEFORE the grid barrier
+//     (ConvPlan), under the drain of the stage's own stores and the wait for the slowest
+//     workgroup; after the barrier a wave issues its activation loads and multiplies.
 #include "common.h"
 
 #include <string.h>
@@ -37,8 +47,9 @@ namespace {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kThreads = 1024;
-constexpr int kSU = 9;                       // k-groups in flight per wave (18 buffer loads)
+constexpr int kSU = 8;                       // k-groups per wave (A and B fragment: 16 buffer loads)
 constexpr int kDescInts = (int)(sizeof(B1Stage) / sizeof(int));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 constexpr int kSpinLimit = 1 << 21;          // ~1-2 s of polling before a block gives up
 static_assert(sizeof(B1Stage) % 16 == 0, "B1Stage must stay 16-byte granular");
 
@@ -71,16 +82,21 @@ __device__ __forceinline__ int xcd_chunk(const int bid, const int nwg) {
     return base + (bid >> 3);
 }
 
-// ---- grid barrier ----------------------------------------------------------------------------
-// Every wave that stored handed-off bytes has drained them before the call.
-__device__ __forceinline__ void grid_barrier(int* sync, const int target, volatile int* lds_fail,
-                                             int* status) {
+// ---- grid barrier, in two halves -----------------------------------------------------------------
+// arrive: every wave that stored handed-off bytes has drained them before the call.
+__device__ __forceinline__ void grid_arrive(int* sync) {
     __syncthreads();
+    if (threadIdx.x == 0)
+        __hip_atomic_fetch_add(sync + (blockIdx.x & 7) * 32, 1, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+}
+// wait: until every workgroup has arrived `target / per_shard` times.  One wave polls the eight
+// shards; its own older loads (a ConvPlan's weight fragments) return first, which costs nothing:
+// the slowest workgroup is still on its way.
+__device__ __forceinline__ void grid_wait(int* sync, const int target, volatile int* lds_fail,
+                                          int* status) {
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
-        if (lane == 0)
-            __hip_atomic_fetch_add(sync + (blockIdx.x & 7) * 32, 1, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
         if (!*lds_fail) {
             for (int spins = 0;;) {
                 int ok = 1;
@@ -105,8 +121,8 @@ __device__ __forceinline__ void grid_barrier(int* sync, const int target, volati
     __syncthreads();
 }
 
-// ---- convolution stage -------------------------------------------------------------------------
-// MODE 0: a k-group is 16 input channels of one filter tap (Cin % 16 == 0, <= 9 taps).
+// ---- convolution stage ------------------------------------------------------------------------
+// MODE 0: a k-group is 16 input channels of one filter tap (Cin % 16 == 0; 3x3 pad 1 or 1x1 pad 0).
 // MODE 1: the stem -- 7x7 taps over the channel-padded image (Cin = 4): a k-group is 4 taps x 4
 //         channels, lane quad kq takes tap 4g + kq; weights are the padded [64][49][4] copy.
 #define B1_FINE(i_)                                                                     \
@@ -114,143 +130,314 @@ __device__ __forceinline__ void grid_barrier(int* sync, const int target, volati
         if (fine && threadIdx.x == 0) fine[i_] = __builtin_amdgcn_s_memrealtime();      \
     } while (0)
 
+// One wave's share of a convolution stage: everything that can be known before the stage's inputs
+// exist.  Scalars are wave-uniform.  A unit is a 16-row x (16 * nt)-channel output tile (nt = 1 or
+// 2: two channel tiles share every activation fragment) times one slice of the reduction index.
+struct ConvPlan {
+    int active, wig, grp, wpt, nk, nt;     // unit assigned?  wave in group, group, waves per unit,
+                                           // k-groups of this wave, channel tiles per unit
+    int ksplit, kj, ticket;                // workgroups per tile, this one's slice, ticket word
+    int relu, relu_post, has_add;
+    int sb, krow4;                         // first k-group of this wave; weight row pitch (bytes)
+    unsigned wOff;                         // this lane's weight row (bytes)
+    unsigned offA[kSU];                    // activation fragment offsets (0xFFFFFFFF: zeros)
+    f32x4 b[kSU];                          // weight fragments, [k-group][channel tile]
+    unsigned e_bn, e_bn_shift;             // folded BatchNorm of the epilogue wave's four channels
+    unsigned e_yoff, e_addoff, e_slab, e_slab_pitch;
+    int e_store;
+};
+
+__device__ __forceinline__ void plan_clear(ConvPlan& p) {
+    p.active = 0; p.wig = 0; p.grp = 0; p.wpt = 16; p.nk = 0; p.nt = 1;
+    p.ksplit = 1; p.kj = 0; p.ticket = 0; p.relu = 0; p.relu_post = 0; p.has_add = 0;
+    p.e_store = 0; p.e_yoff = 0u; p.e_addoff = 0xFFFFFFFFu; p.e_slab = 0u; p.e_slab_pitch = 0u;
+    p.e_bn = 0u; p.e_bn_shift = 0u; p.sb = 0; p.krow4 = 0; p.wOff = 0u;
+#pragma unroll
+    for (int u = 0; u < kSU; ++u) { p.offA[u] = 0xFFFFFFFFu; p.b[u] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+}
+
+// The weight fragments of a plan: slot of (k-group u, channel tile j) = u * nt + j (host: nk * nt
+// <= kSU).  OHWI weights: reduction index tap * Cin + 16 cg = 16 s, i.e. 64 s bytes into the row.
 template <int MODE>
-__device__ __forceinline__ void conv_stage(const B1Stage* st, const rsrc_t rsW, const rsrc_t rsP,
-                                           float* red, const int nblk, const int lb,
-                                           long long* fine) {
+__device__ __forceinline__ void plan_issue_b(ConvPlan& p, const rsrc_t rsW, const rsrc_t rsP) {
+    const rsrc_t rsB = MODE == 1 ? rsW : rsP;
+    const int kq = (threadIdx.x & 63) >> 4;
+#pragma unroll
+    for (int i = 0; i < kSU; ++i) {
+        if (i < p.nk * p.nt) {
+            const int u = p.nt == 2 ? (i >> 1) : i, j = p.nt == 2 ? (i & 1) : 0;
+            const int s = p.sb + u;
+            unsigned offB;
+            if (MODE == 0) {
+                offB = p.wOff + (unsigned)(s * 64) + (unsigned)(j * 16 * p.krow4);
+            } else {
+                const int tap = 4 * s + kq;
+                offB = tap < 49 ? p.wOff + (unsigned)(tap * 16) : 0xFFFFFFFFu;
+            }
+            p.b[i] = ld_const(rsB, offB);
+        }
+    }
+}
+
+// defer_b: the wave loads its weight fragments later (plan_issue_b): the
+// polling wave after its poll (a poll is an in-order vector load and would otherwise wait behind
+// them), an epilogue wave after the drain of its stores.
+template <int MODE>
+__device__ __forceinline__ void plan_conv(ConvPlan& p, const B1Stage* st, const rsrc_t rsW,
+                                          const rsrc_t rsP, const int nblk, const bool defer_b) {
     const int lane = threadIdx.x & 63, wave = RFL(threadIdx.x >> 6);
     const int r = lane & 15, kq = lane >> 4;
-    const int wpt = RFL(st->wpt);
+    const i32x4 hd = *reinterpret_cast<const i32x4*>(st);           // type, wpt, nunits0, total
+    const int wpt = RFL(hd[1]), nunits0 = RFL(hd[2]), total = RFL(hd[3]);
     const int wshift = wpt == 16 ? 4 : wpt == 8 ? 3 : wpt == 4 ? 2 : 1;
-    const int groups = 16 >> wshift;
     const int grp = wave >> wshift, wig = wave & (wpt - 1);
-    const int total = RFL(st->total_tiles);
-    const int slots = nblk * groups;
-    const int npass = (total + slots - 1) / slots;
-    const int nt0 = RFL(st->c[0].ntiles);
-    const rsrc_t rsB = MODE == 1 ? rsW : rsP;
-
-    for (int pass = 0; pass < npass; ++pass) {
-        int t = pass * slots + grp * nblk + lb;
-        const bool active = t < total;                       // wave-uniform
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        f32x4 e_sc = {1.f, 1.f, 1.f, 1.f}, e_sh = {0.f, 0.f, 0.f, 0.f}, e_add = {0.f, 0.f, 0.f, 0.f};
-        unsigned e_yoff = 0u;
-        bool e_store = false;
-        int e_relu = 0, e_relu_post = 0;
-        if (active) {
-            const int pi = t >= nt0 ? 1 : 0;
-            if (pi) t -= nt0;
-            const B1Conv* c = &st->c[pi];
-            const int H = RFL(c->H), W = RFL(c->W), Cin = RFL(c->Cin), Wo = RFL(c->Wo);
-            const int Cout = RFL(c->Cout), K = RFL(c->K), stride = RFL(c->stride), pad = RFL(c->pad);
-            const int M = RFL(c->M), nmt = RFL(c->nmt), S = RFL(c->S), cshift = RFL(c->cshift);
-            const unsigned x_off = (unsigned)RFL(c->x_off), w_off = (unsigned)RFL(c->w_off);
-            const int nt = t / nmt, mt = t - nt * nmt;       // m fastest: tiles sharing weights adjoin
-            const int m0 = mt * 16, n0 = nt * 16;
-            if (wig == 0) {      // the group's epilogue wave fetches its operands up front
-                const int row = lane >> 2, c4 = (lane & 3) * 4;
-                const int m = m0 + row;
-                e_store = m < M;
-                const unsigned eo = (unsigned)((m * Cout + n0 + c4) * 4);
-                e_yoff = (unsigned)RFL(c->y_off) + eo;
-                if (RFL(c->has_add))
-                    e_add = ld_act(rsW, e_store ? (unsigned)RFL(c->add_off) + eo : 0xFFFFFFFFu);
-                e_relu = RFL(c->relu);
-                e_relu_post = RFL(c->relu_post);
-            }
-            B1_FINE(0);
-            // ---- this wave's slice of the reduction index
-            const int per = (S + wpt - 1) >> wshift;
-            const int sb = wig * per, se = min(S, sb + per);
-            const int m = m0 + r;
-            const int oh = m / Wo, ow = m - oh * Wo;
-            const int hb = oh * stride - pad, wb = ow * stride - pad;
-            unsigned rowOff = 0u, rowMask = 0u, wOff = 0u;
-            int tapA_v = 0;
-            if (MODE == 0) {
-                const int ntaps = K * K;
-                if (m < M)
-                    for (int kh = 0; kh < K; ++kh)
-                        for (int kw = 0; kw < K; ++kw) {
-                            const int h = hb + kh, w = wb + kw;
-                            if (h >= 0 && w >= 0 && h < H && w < W) rowMask |= 1u << (kh * K + kw);
-                        }
-                rowOff = x_off + (unsigned)(((hb * W + wb) * Cin + kq * 4) * 4);
-                wOff = w_off + (unsigned)((((n0 + r) * ntaps) * Cin + kq * 4) * 4);
-                if (lane < ntaps) tapA_v = ((lane / K) * W + lane % K) * Cin * 4;
-            }
-            B1_FINE(1);
-            for (int s0 = sb; s0 < se; s0 += kSU) {
-                f32x4 av[kSU], bv[kSU];
-#pragma unroll
-                for (int u = 0; u < kSU; ++u) {
-                    const int s = s0 + u;                     // wave-uniform
-                    const bool live = s < se;
-                    unsigned offA, offB;
-                    if (MODE == 0) {
-                        const int tap = live ? (s >> cshift) : 0;
-                        const int cg = s & ((1 << cshift) - 1);
-                        const unsigned toff = (unsigned)__builtin_amdgcn_readlane(tapA_v, tap) +
-                                              (unsigned)(cg * 64);
-                        offA = (live && ((rowMask >> tap) & 1u)) ? rowOff + toff : 0xFFFFFFFFu;
-                        offB = live ? wOff + (unsigned)((tap * Cin + cg * 16) * 4) : 0xFFFFFFFFu;
-                    } else {
-                        const int tap = 4 * s + kq;           // per lane
-                        const int kh = tap / 7, kw = tap - 7 * kh;
-                        const int h = hb + kh, w = wb + kw;
-                        const bool tv = live && tap < 49;
-                        const bool ok = tv && m < M && h >= 0 && w >= 0 && h < H && w < W;
-                        offA = ok ? x_off + (unsigned)((h * W + w) * 16) : 0xFFFFFFFFu;
-                        offB = tv ? w_off + (unsigned)(((n0 + r) * 49 + tap) * 16) : 0xFFFFFFFFu;
-                    }
-                    av[u] = ld_act(rsW, offA);
-                    bv[u] = ld_const(rsB, offB);
-                }
-                __builtin_amdgcn_sched_barrier(0);    // every load in flight before the first MFMA
-                B1_FINE(2);
-#pragma unroll
-                for (int u = 0; u < kSU; ++u)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][e], bv[u][e], acc, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            B1_FINE(3);
-            if (wig == 0) {      // folded BatchNorm of the tile's channels: lands under the LDS hand-over
-                const int c4 = (lane & 3) * 4;
-                e_sc = ld_const(rsW, (unsigned)RFL(c->scale_off) + (unsigned)((n0 + c4) * 4));
-                e_sh = ld_const(rsW, (unsigned)RFL(c->shift_off) + (unsigned)((n0 + c4) * 4));
-            }
-            // C/D map of 16x16x4: col = lane & 15, row = 4 * (lane >> 4) + i
-#pragma unroll
-            for (int i = 0; i < 4; ++i) red[wave * 256 + (4 * kq + i) * 16 + r] = acc[i];
+    // One pass (host: slots >= units): wave group g of the blocks takes units [g nblk, (g+1) nblk).
+    // Its units are dealt to the 8 XCDs in equal contiguous chunks -- every L2 carries an eighth
+    // of them, tiles that share weights meet in one L2 -- blocks b and b + 8 sharing an XCD
+    // (speed only).
+    const int ng = min(nblk, total - grp * nblk);              // units of this wave group
+    const int q = (ng + 7) >> 3;                               // ... per XCD
+    const int idx = (int)blockIdx.x >> 3, within = ((int)blockIdx.x & 7) * q + idx;
+    int t = grp * nblk + within;
+    plan_clear(p);
+    p.active = idx < q && within < ng;
+    p.wig = wig; p.grp = grp; p.wpt = wpt;
+    if (!p.active) return;
+    const int pi = t >= nunits0 ? 1 : 0;
+    if (pi) t -= nunits0;
+    // the whole descriptor in eight LDS reads, then scalars
+    const i32x4* cv = reinterpret_cast<const i32x4*>(&st->c[pi]);
+    const i32x4 q0 = cv[0], q1 = cv[1], q2 = cv[2], q3 = cv[3], q4 = cv[4], q5 = cv[5], q6 = cv[6],
+                q7 = cv[7];
+    const unsigned x_off = (unsigned)RFL(q0[0]), y_off = (unsigned)RFL(q0[1]);
+    const unsigned add_off = (unsigned)RFL(q0[2]), w_off = (unsigned)RFL(q0[3]);
+    const unsigned scale_off = (unsigned)RFL(q1[0]), shift_off = (unsigned)RFL(q1[1]);
+    const int H = RFL(q1[2]), W = RFL(q1[3]);
+    const int Cin = RFL(q2[0]), Wo = RFL(q2[1]), Cout = RFL(q2[2]), K = RFL(q2[3]);
+    const int stride = RFL(q3[0]), M = RFL(q3[1]), nmt = RFL(q3[2]);
+    const int S = RFL(q4[0]), cshift = RFL(q4[1]), krow4 = RFL(q4[2]);
+    const unsigned wo_magic = (unsigned)RFL(q5[2]), nmt_magic = (unsigned)RFL(q5[3]);
+    const int ksplit = RFL(q6[0]), sper = RFL(q6[1]), per = RFL(q6[2]);
+    const unsigned ks_magic = (unsigned)RFL(q6[3]);
+    const int nt = RFL(q7[3]);
+    p.relu = RFL(q4[3]); p.relu_post = RFL(q5[0]); p.has_add = RFL(q5[1]); p.nt = nt;
+    // unit -> (tile, k-slice); tile -> (channel tile, row tile), rows fastest
+    const int tile = (int)(((unsigned)t * ks_magic) >> 20), kj = t - tile * ksplit;
+    const int ntile = (int)(((unsigned)tile * nmt_magic) >> 20), mt = tile - ntile * nmt;
+    const int m0 = mt * 16, n0 = ntile * 16 * nt;
+    p.ksplit = ksplit; p.kj = kj; p.ticket = RFL(q7[1]) + tile;
+    // ---- this wave's slice of the reduction index
+    const int ub = kj * sper, ue = min(S, ub + sper);
+    const int sb = ub + wig * per, se = min(ue, sb + per);
+    p.nk = max(se - sb, 0);
+    const int m = m0 + r;
+    const int oh = (int)(((unsigned)m * wo_magic) >> 20), ow = m - oh * Wo;
+    unsigned rowOff = 0u, rowMask = 0u, wOff = 0u;
+    int tapA_v = 0, hb = 0, wb = 0;
+    if (MODE == 0) {
+        if (K == 3) {          // pad 1: tap (kh, kw) is inside iff 0 <= hb + kh < H, same for w
+            hb = oh * stride - 1; wb = ow * stride - 1;
+            const unsigned hm = (hb >= 0 ? 1u : 0u) | 2u | (hb + 2 < H ? 4u : 0u);
+            const unsigned wm = (wb >= 0 ? 1u : 0u) | 2u | (wb + 2 < W ? 4u : 0u);
+            rowMask = ((hm & 1u) ? wm : 0u) | ((hm & 2u) ? wm << 3 : 0u) | ((hm & 4u) ? wm << 6 : 0u);
+            const int kh = (lane * 11) >> 5;                     // lane / 3 for lane < 16
+            tapA_v = (kh * W + (lane - 3 * kh)) * Cin * 4;
+        } else {               // 1x1, pad 0
+            hb = oh * stride; wb = ow * stride;
+            rowMask = 1u;
         }
-        B1_FINE(4);
-        __syncthreads();
-        B1_FINE(5);
-        if (active && wig == 0) {
-            const int row = lane >> 2, c4 = (lane & 3) * 4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            for (int w = 0; w < wpt; ++w)                     // wave order: deterministic
-                v += *reinterpret_cast<const f32x4*>(red + ((grp << wshift) + w) * 256 + row * 16 + c4);
-            v = v * e_sc + e_sh;
-            if (e_relu) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-            }
-            v += e_add;
-            if (e_relu_post) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-            }
-            if (e_store) st_act(rsW, e_yoff, v);
-            B1_FINE(6);
-            drain_stores();
-        }
-        B1_FINE(7);
-        __syncthreads();
+        if (m >= M) rowMask = 0u;
+        rowOff = x_off + (unsigned)(((hb * W + wb) * Cin + kq * 4) * 4);
+        wOff = w_off + (unsigned)((n0 + r) * krow4 + kq * 16);
+    } else {
+        hb = oh * 2 - 3; wb = ow * 2 - 3;
     }
+#pragma unroll
+    for (int u = 0; u < kSU; ++u) {
+        const int s = sb + u;                                 // wave-uniform
+        if (u < p.nk) {
+            if (MODE == 0) {
+                const int tap = s >> cshift;
+                const int cg = s & ((1 << cshift) - 1);
+                const unsigned toff = (unsigned)__builtin_amdgcn_readlane(tapA_v, tap) +
+                                      (unsigned)(cg * 64);
+                p.offA[u] = ((rowMask >> tap) & 1u) ? rowOff + toff : 0xFFFFFFFFu;
+            } else {
+                const int tap = 4 * s + kq;                   // per lane
+                const int kh = (tap * 37) >> 8, kw = tap - 7 * kh;       // tap / 7, tap < 56
+                const int h = hb + kh, w = wb + kw;
+                const bool ok = tap < 49 && m < M && h >= 0 && w >= 0 && h < H && w < W;
+                p.offA[u] = ok ? x_off + (unsigned)((h * W + w) * 16) : 0xFFFFFFFFu;
+            }
+        }
+    }
+    p.sb = sb; p.krow4 = krow4;
+    p.wOff = MODE == 0 ? wOff : w_off + (unsigned)((n0 + r) * 49 * 16);
+    if (!defer_b) plan_issue_b<MODE>(p, rsW, rsP);
+    if (wig == 0) {          // the unit's epilogue wave: output / residual / slab addresses, BatchNorm
+        const int row = lane >> 2, c4 = (lane & 3) * 4;
+        const int me = m0 + row;
+        p.e_store = me < M;
+        const unsigned eo = (unsigned)((me * Cout + n0 + c4) * 4);
+        p.e_yoff = y_off + eo;
+        p.e_addoff = (p.has_add && p.e_store) ? add_off + eo : 0xFFFFFFFFu;
+        p.e_slab_pitch = (unsigned)(nmt * 16 * Cout * 4);
+        p.e_slab = (unsigned)RFL(q7[0]) + eo;
+        p.e_bn = scale_off + (unsigned)((n0 + c4) * 4);
+        p.e_bn_shift = shift_off - scale_off;
+    }
+}
+
+template <int WPT>
+__device__ __forceinline__ f32x4 sum_partials(const float* rp) {
+    constexpr int G = WPT < 8 ? WPT : 8;        // reads in flight at a time
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w0 = 0; w0 < WPT; w0 += G) {
+        f32x4 t[G];
+#pragma unroll
+        for (int w = 0; w < G; ++w) t[w] = *reinterpret_cast<const f32x4*>(rp + (w0 + w) * 512);
+        __builtin_amdgcn_sched_barrier(0);      // the reads in flight, then the adds in wave order
+#pragma unroll
+        for (int w = 0; w < G; ++w) v = (w0 + w == 0) ? t[0] : v + t[w];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    return v;
+}
+
+// what the epilogue wave of a unit fetched for its (up to two) channel tiles
+struct ConvEpi { f32x4 add0, add1, sc0, sc1, sh0, sh1; };
+
+// Multiply phase (every wave): activation loads, MFMAs, partial tiles to LDS [wave][nt][16][16].
+__device__ __forceinline__ void exec_conv_main(const ConvPlan& p, ConvEpi& ep, const rsrc_t rsW,
+                                               float* red, long long* fine) {
+    const int lane = threadIdx.x & 63, wave = RFL(threadIdx.x >> 6);
+    const int r = lane & 15, kq = lane >> 4;
+    ep.add0 = ep.add1 = ep.sh0 = ep.sh1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    ep.sc0 = ep.sc1 = f32x4{1.f, 1.f, 1.f, 1.f};
+    B1_FINE(0);
+    const int nk = RFL(p.nk), nt = RFL(p.nt), wig = RFL(p.wig), has_add = RFL(p.has_add);
+    if (RFL(p.active)) {
+        f32x4 av[kSU];
+#pragma unroll
+        for (int u = 0; u < kSU; ++u)
+            if (u < nk) av[u] = ld_act(rsW, p.offA[u]);
+        if (wig == 0 && has_add) {
+            ep.add0 = ld_act(rsW, p.e_addoff);
+            if (nt == 2)
+                ep.add1 = ld_act(rsW, p.e_addoff == 0xFFFFFFFFu ? 0xFFFFFFFFu : p.e_addoff + 64u);
+        }
+        __builtin_amdgcn_sched_barrier(0);        // every load in flight before the first MFMA
+        B1_FINE(1);
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        if (nt == 1) {
+#pragma unroll
+            for (int u = 0; u < kSU; ++u) {
+                if (u < nk) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (u & 1)
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][e], p.b[u][e], acc1, 0, 0, 0);
+                        else
+                            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][e], p.b[u][e], acc0, 0, 0, 0);
+                    }
+                }
+            }
+            acc0 += acc1;
+        } else {
+#pragma unroll
+            for (int u = 0; u < kSU / 2; ++u) {
+                if (u < nk) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][e], p.b[2 * u][e], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][e], p.b[2 * u + 1][e], acc1, 0, 0, 0);
+                    }
+                }
+            }
+        }
+        B1_FINE(2);
+        if (wig == 0) {          // folded BatchNorm: lands under the LDS hand-over
+            ep.sc0 = ld_const(rsW, p.e_bn);
+            ep.sh0 = ld_const(rsW, p.e_bn + p.e_bn_shift);
+            if (nt == 2) {
+                ep.sc1 = ld_const(rsW, p.e_bn + 64u);
+                ep.sh1 = ld_const(rsW, p.e_bn + p.e_bn_shift + 64u);
+            }
+        }
+        // C/D map of 16x16x4: col = lane & 15, row = 4 * (lane >> 4) + i
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[wave * 512 + (4 * kq + i) * 16 + r] = acc0[i];
+        if (nt == 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) red[wave * 512 + 256 + (4 * kq + i) * 16 + r] = acc1[i];
+        }
+    }
+    B1_FINE(3);
+    __syncthreads();
+    B1_FINE(4);
+}
+
+// Epilogue of a unit (its first wave): partial tiles summed in wave order, split-K combine by
+// ticket, folded BatchNorm / ReLU / residual, sc1 store.  Returns true if stores are in flight.
+__device__ __forceinline__ bool exec_conv_epilogue(const ConvPlan& p, const ConvEpi& ep,
+                                                   const rsrc_t rsW, const float* red, int* sync,
+                                                   long long* fine) {
+    const int lane = threadIdx.x & 63;
+    const int row = lane >> 2, c4 = (lane & 3) * 4;
+    const int nt = RFL(p.nt), wpt = RFL(p.wpt), grp = RFL(p.grp), ksplit = RFL(p.ksplit);
+    const int kj = RFL(p.kj), ticket = RFL(p.ticket), relu = RFL(p.relu), relu_post = RFL(p.relu_post);
+    bool stored = false;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        if (j < nt) {
+            const float* rp = red + (grp * wpt) * 512 + j * 256 + row * 16 + c4;
+            f32x4 v = wpt == 16 ? sum_partials<16>(rp) : wpt == 8 ? sum_partials<8>(rp)
+                      : wpt == 4 ? sum_partials<4>(rp) : sum_partials<2>(rp);
+            bool finish = true;
+            if (j == 0 && ksplit > 1) {      // (host: split units have one channel tile)
+                // park the partial tile, take a ticket; the last arriver sums the slices in order
+                if (p.e_store) st_act(rsW, p.e_slab + (unsigned)kj * p.e_slab_pitch, v);
+                drain_stores();
+                int old = 0;
+                if (lane == 0)
+                    old = __hip_atomic_fetch_add(sync + 9 * 32 + ticket, 1, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+                old = RFL(old);
+                finish = old == ksplit - 1;
+                if (finish) {
+                    if (lane == 0)      // ready for the next launch; nobody else touches it any more
+                        __hip_atomic_store(sync + 9 * 32 + ticket, 0, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                    f32x4 sl[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        sl[k] = ld_act(rsW, (k < ksplit && p.e_store)
+                                                ? p.e_slab + (unsigned)k * p.e_slab_pitch : 0xFFFFFFFFu);
+                    v = sl[0];
+#pragma unroll
+                    for (int k = 1; k < 4; ++k)
+                        if (k < ksplit) v += sl[k];
+                }
+            }
+            if (finish) {
+                v = v * (j ? ep.sc1 : ep.sc0) + (j ? ep.sh1 : ep.sh0);
+                if (relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                v += j ? ep.add1 : ep.add0;
+                if (relu_post) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (p.e_store) st_act(rsW, p.e_yoff + 64u * j, v);
+                stored = true;
+            }
+        }
+    }
+    B1_FINE(5);
+    return stored;
 }
 
 // ---- uint8 HWC frame -> normalised NHWC4 (preprocess_image, autonomous_drive.py:897-902) -------
@@ -270,6 +457,42 @@ __device__ __forceinline__ void pre_stage(const B1Stage* st, const B1Launch& a, 
         stored = true;
     }
     if (stored) drain_stores();
+}
+
+// ---- speed encoder (autonomous_drive.py:371-374, 391) ----------------------------------------
+// It depends on the speed alone: the last block evaluates it AFTER it has arrived at the first
+// barrier (nobody waits for it: its consumer is 36 stages away), arithmetic order of
+// heads_small_pre_kernel (heads_optim.hip).
+__device__ __forceinline__ void speed_encoder(const B1Stage* st, const B1Launch& a, const rsrc_t rsW,
+                                              const rsrc_t rsP, float* s1) {
+    const B1Head* h = &st->h;
+    const int tid = threadIdx.x, lane = tid & 63, wave = RFL(tid >> 6);
+    if (tid < 128) {
+        const float w0 = ld_const1(rsP, (unsigned)RFL(h->se_w0) + (unsigned)tid * 4u);
+        const float b0 = ld_const1(rsP, (unsigned)RFL(h->se_b0) + (unsigned)tid * 4u);
+        s1[tid] = fmaxf(fmaf(a.speed[0], w0, 0.f) + b0, 0.f);
+    }
+    const unsigned w1 = (unsigned)RFL(h->se_w1), b1 = (unsigned)RFL(h->se_b1);
+    float wl[8], wh[8], bb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {                  // weights do not wait for layer 1
+        const int o = wave * 8 + j;
+        wl[j] = ld_const1(rsP, w1 + (unsigned)((o * 128 + lane) * 4));
+        wh[j] = ld_const1(rsP, w1 + (unsigned)((o * 128 + lane + 64) * 4));
+        bb[j] = ld_const1(rsP, b1 + (unsigned)o * 4u);
+    }
+    __syncthreads();
+    const float xa = s1[lane], xb = s1[lane + 64];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float v = fmaf(xb, wh[j], xa * wl[j]);
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) v += __shfl_xor(v, sft);
+        if (lane == 0)
+            st_act1(rsW, (unsigned)RFL(h->y_off[0]) + (unsigned)(wave * 8 + j) * 4u,
+                    fmaxf(v + bb[j], 0.f));
+    }
+    drain_stores();
 }
 
 // ---- MaxPool2d(3, 2, 1) on NHWC (torch: first maximum in scan order wins) ---------------------
@@ -317,7 +540,7 @@ __device__ __forceinline__ void pool_stage(const B1Stage* st, const rsrc_t rsW, 
 // (arithmetic order of heads_small_layer_kernel / heads_small_pre_kernel in heads_optim.hip:
 //  the two paths agree bit for bit given the same inputs)
 __device__ __forceinline__ void head_stage(const B1Stage* st, const B1Launch& a, const rsrc_t rsW,
-                                           const rsrc_t rsP, float* hx, float* s1, const int nblk) {
+                                           const rsrc_t rsP, float* hx, const int nblk) {
     const B1Head* h = &st->h;
     const int tid = threadIdx.x, lane = tid & 63, wave = RFL(tid >> 6);
     const long long cmd = a.cmd[0];
@@ -331,28 +554,22 @@ __device__ __forceinline__ void head_stage(const B1Stage* st, const B1Launch& a,
         if (blockIdx.x == 0 && tid == 0) a.status[0] = (cmd < 0 || cmd > 3) ? 1 : 0;
         const int HW = RFL(h->featHW), C = RFL(h->featC);
         const unsigned fo = (unsigned)RFL(h->feat_off);
-        if (tid < (C >> 2)) {              // AdaptiveAvgPool2d(1,1) + Flatten (:369)
+        if (tid < (C >> 2)) {              // AdaptiveAvgPool2d(1,1) + Flatten (:369); pixel order
             f32x4 s = {0.f, 0.f, 0.f, 0.f};
-            for (int p = 0; p < HW; ++p) s += ld_act(rsW, fo + (unsigned)((p * C + tid * 4) * 4));
-            *reinterpret_cast<f32x4*>(x0 + tid * 4) = s / (float)HW;
-        } else if (tid >= 256 && tid < 384) {      // speed encoder layer 1 (:371-372, 391)
-            const int t = tid - 256;
-            const float w0 = ld_const1(rsP, (unsigned)RFL(h->se_w0) + (unsigned)t * 4u);
-            const float b0 = ld_const1(rsP, (unsigned)RFL(h->se_b0) + (unsigned)t * 4u);
-            s1[t] = fmaxf(fmaf(a.speed[0], w0, 0.f) + b0, 0.f);
-        }
-        __syncthreads();
-        {                                           // speed encoder layer 2 (:373-374)
-            const float xa = s1[lane], xb = s1[lane + 64];
-            const unsigned w1 = (unsigned)RFL(h->se_w1), b1 = (unsigned)RFL(h->se_b1);
-            for (int o = wave * 8; o < wave * 8 + 8; ++o) {
-                const float wl = ld_const1(rsP, w1 + (unsigned)((o * 128 + lane) * 4));
-                const float wh = ld_const1(rsP, w1 + (unsigned)((o * 128 + lane + 64) * 4));
-                float v = fmaf(xb, wh, xa * wl);
+            for (int p0 = 0; p0 < HW; p0 += 8) {
+                f32x4 v[8];
 #pragma unroll
-                for (int sft = 32; sft > 0; sft >>= 1) v += __shfl_xor(v, sft);
-                if (lane == 0) x0[C + o] = fmaxf(v + ld_const1(rsP, b1 + (unsigned)o * 4u), 0.f);
+                for (int j = 0; j < 8; ++j)        // eight loads in flight; past the end: zeros
+                    v[j] = ld_act(rsW, p0 + j < HW ? fo + (unsigned)(((p0 + j) * C + tid * 4) * 4)
+                                                   : 0xFFFFFFFFu);
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (p0 + j < HW) s += v[j];
             }
+            *reinterpret_cast<f32x4*>(x0 + tid * 4) = s / (float)HW;
+        } else if (tid >= 256 && tid < 288) {      // speed features, computed in stage 0
+            *reinterpret_cast<f32x4*>(x0 + C + (tid - 256) * 4) =
+                ld_act(rsW, (unsigned)RFL(h->x_off[0]) + (unsigned)(tid - 256) * 16u);
         }
         x1 = x0;                                     // the speed head reads the visual half (:393)
     } else {
@@ -411,25 +628,30 @@ __device__ __forceinline__ void head_stage(const B1Stage* st, const B1Launch& a,
     if (stored) drain_stores();
 }
 
+__device__ __forceinline__ const B1Stage* desc_stage(const int* desc, const int s) {
+    return reinterpret_cast<const B1Stage*>(desc + s * kDescInts);
+}
+
 __global__ __launch_bounds__(kThreads) void infer_b1_kernel(const B1Launch a) {
-    __shared__ __attribute__((aligned(16))) int desc[2][kDescInts];
-    __shared__ __attribute__((aligned(16))) float red[16 * 256];
+    __shared__ __attribute__((aligned(16))) int desc[kB1MaxStages * kDescInts];
+    __shared__ __attribute__((aligned(16))) float red[16 * 512];
     __shared__ __attribute__((aligned(16))) float hx[2 * 640];
     __shared__ float s1[128];
     __shared__ int fail;
     const int tid = threadIdx.x;
     const int nblk = gridDim.x;
-    const int lb = xcd_chunk(blockIdx.x, nblk);
     const rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)a.ws, 0, (int)(unsigned)a.ws_bytes,
                                                          0x00020000);
     const rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc((void*)a.params, 0,
                                                          (int)(unsigned)a.param_bytes, 0x00020000);
+    const int nstages = a.nstages;
     // epoch base of the monotonic counters: advanced by block 0 at the end of the previous launch
     int base;
     asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)"
                  : "=&v"(base) : "v"(a.sync + 8 * 32) : "memory");
     base = RFL(base);
-    if (tid < kDescInts) desc[0][tid] = reinterpret_cast<const int*>(a.table)[tid];
+    for (int i = tid; i < nstages * kDescInts; i += kThreads)      // the stage table, once
+        desc[i] = reinterpret_cast<const int*>(a.table)[i];
     if (tid == 0) {
         fail = 0;
         if (blockIdx.x == 0)     // a give-up (>= 1 s of polling) cannot race this store
@@ -437,29 +659,48 @@ __global__ __launch_bounds__(kThreads) void infer_b1_kernel(const B1Launch a) {
     }
     __syncthreads();
     const int per_shard = nblk >> 3;
-    const int nstages = a.nstages;
+    const bool poller = RFL(tid >> 6) == 0;            // wave 0 (a scalar: no divergent plans)
     for (int s = 0; s < nstages; ++s) {
-        const B1Stage* st = reinterpret_cast<const B1Stage*>(desc[s & 1]);
-        int next_word = 0;                    // next stage's descriptor travels under this stage
-        if (s + 1 < nstages && tid < kDescInts)
-            next_word = reinterpret_cast<const int*>(a.table + s + 1)[tid];
-        const int failed = *reinterpret_cast<volatile int*>(&fail);
+        const B1Stage* st = desc_stage(desc, s);
+        const int type = RFL(st->type);
+        int failed = RFL(*reinterpret_cast<volatile int*>(&fail));     // wave-uniform
+        // The plan of this stage (addresses, weight fragments in flight) is made between this
+        // workgroup's arrival at the barrier (end of the previous iteration) and its wait: while
+        // the slowest workgroup is still on its way.  It lives inside one iteration.
+        ConvPlan plan;
+        const bool defer = poller && s > 0;
+        if (!failed && type == B1_CONV) plan_conv<0>(plan, st, rsW, rsP, nblk, defer);
+        else if (!failed && type == B1_STEM) plan_conv<1>(plan, st, rsW, rsP, nblk, defer);
+        else plan_clear(plan);
+        if (s > 0) {
+            grid_wait(a.sync, base + s * per_shard, &fail, a.status);
+            failed = RFL(*reinterpret_cast<volatile int*>(&fail));
+            if (defer && !failed) {
+                if (type == B1_CONV) plan_issue_b<0>(plan, rsW, rsP);
+                else if (type == B1_STEM) plan_issue_b<1>(plan, rsW, rsP);
+            }
+        }
         if (a.stamps && blockIdx.x == 0 && tid == 0) a.stamps[s] = __builtin_amdgcn_s_memrealtime();
-        if (!failed) {
-            const int type = RFL(st->type);
-            long long* fine = (a.stamps && blockIdx.x == 0)
-                                  ? a.stamps + 2 * (kB1MaxStages + 1) + 8 * s : nullptr;
-            if (type == B1_CONV) conv_stage<0>(st, rsW, rsP, red, nblk, lb, fine);
-            else if (type == B1_STEM) conv_stage<1>(st, rsW, rsP, red, nblk, lb, fine);
-            else if (type == B1_POOL) pool_stage(st, rsW, nblk);
+        long long* fine = (a.stamps && blockIdx.x == 0)
+                              ? a.stamps + 2 * (kB1MaxStages + 1) + 8 * s : nullptr;
+        if (!failed && (type == B1_CONV || type == B1_STEM)) {
+            ConvEpi ep;
+            exec_conv_main(plan, ep, rsW, red, fine);
+            if (RFL(plan.active) && RFL(plan.wig) == 0) {
+                if (exec_conv_epilogue(plan, ep, rsW, red, a.sync, fine)) drain_stores();
+            }
+        } else if (!failed) {
+            if (type == B1_POOL) pool_stage(st, rsW, nblk);
             else if (type == B1_PRE) pre_stage(st, a, rsW, nblk);
-            else head_stage(st, a, rsW, rsP, hx, s1, nblk);
+            else head_stage(st, a, rsW, rsP, hx, nblk);     // (these drain their own stores)
         }
         if (a.stamps && blockIdx.x == 0 && tid == 0)
             a.stamps[kB1MaxStages + 1 + s] = __builtin_amdgcn_s_memrealtime();
+        if (a.stamps && tid == 0)      // diagnostics: when each workgroup was done with the stage
+            a.stamps[10 * (kB1MaxStages + 1) + s * nblk + blockIdx.x] = __builtin_amdgcn_s_memrealtime();
         if (s + 1 < nstages) {
-            if (tid < kDescInts) desc[(s + 1) & 1][tid] = next_word;
-            grid_barrier(a.sync, base + (s + 1) * per_shard, &fail, a.status);
+            grid_arrive(a.sync);
+            if (s == 0 && (int)blockIdx.x == nblk - 1) speed_encoder(st, a, rsW, rsP, s1);
         }
     }
     if (blockIdx.x == 0 && tid == 0) {

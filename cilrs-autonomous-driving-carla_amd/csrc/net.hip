@@ -16,6 +16,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -309,7 +310,7 @@ struct cilrs_net {
     TransposeF16Table tr_table;
     // persistent single-frame kernel (infer_b1.hip): stage table + barrier counters in the
     // workspace (offsets in floats; 0 = this plan has none), uploaded once per workspace
-    size_t b1_table = 0, b1_sync = 0, b1_stamps = 0;
+    size_t b1_table = 0, b1_sync = 0, b1_stamps = 0, b1_slabs = 0, b1_slab_floats = 0;
     std::vector<B1Stage> b1_host;
     int b1_blocks = -1;                    // resident grid (one workgroup per CU); -1 = not asked yet
     const void* b1_ready_for = nullptr;
@@ -862,7 +863,16 @@ int cilrs_net_create_ex(int variant, int batch, int height, int width, unsigned 
     if (batch == 1 && variant == 0) {
         n->b1_table = bump.take(kB1MaxStages * sizeof(B1Stage) / sizeof(float));
         n->b1_sync = bump.take(kB1SyncInts);
-        n->b1_stamps = bump.take(2 * 10 * (kB1MaxStages + 1));
+        n->b1_stamps = bump.take(2 * (10 * (kB1MaxStages + 1) + kB1MaxStages * 512));
+        // split-K partial tiles: up to 4 slices of the largest [16-row tiles][Cout] output, twice
+        // (a stage may hold two convolutions)
+        size_t big = 0;
+        for (size_t ci = 1; ci < A.convs.size(); ++ci) {
+            const size_t o = (size_t)cdiv(n->cg[ci].M, 16) * 16 * A.convs[ci].cout;
+            if (o > big) big = o;
+        }
+        n->b1_slab_floats = 2 * 4 * big;
+        n->b1_slabs = bump.take(n->b1_slab_floats);
     }
     n->ws_bytes = bump.off * sizeof(float);
     *out = n;
@@ -1374,10 +1384,14 @@ static int b1_build(cilrs_net* net, int nblk) {
     std::vector<B1Stage>& T = net->b1_host;
     T.clear();
     auto fb = [](size_t floats) { return (unsigned)(floats * sizeof(float)); };
-    auto pick_wpt = [&](int total) {
-        for (int w : {16, 8, 4, 2})
-            if (total <= nblk * (16 / w)) return w;
-        return 2;
+    bool magic_ok = true;
+    auto magic20 = [&](int d, int xmax) {        // x / d == (x * magic) >> 20 for 0 <= x <= xmax
+        const unsigned mg = ((1u << 20) + (unsigned)d - 1u) / (unsigned)d;
+        for (int x = 0; x <= xmax; ++x)
+            if ((unsigned)(((unsigned long long)x * mg) >> 20) != (unsigned)(x / d) ||
+                (unsigned long long)x * mg >= (1ull << 32))
+                magic_ok = false;
+        return mg;
     };
     auto conv_desc = [&](int ci, size_t x, bool has_add, size_t add, int relu, int relu_post) {
         const ConvT& c = A.convs[ci];
@@ -1386,39 +1400,93 @@ static int b1_build(cilrs_net* net, int nblk) {
         memset(&d, 0, sizeof(d));
         d.x_off = fb(x); d.y_off = fb(g.z); d.add_off = has_add ? fb(add) : 0u;
         d.scale_off = fb(g.stats + 2 * (size_t)c.cout); d.shift_off = fb(g.stats + 3 * (size_t)c.cout);
-        d.H = g.H; d.W = g.W; d.Ho = g.Ho; d.Wo = g.Wo; d.Cout = c.cout; d.K = c.k;
-        d.stride = c.stride; d.pad = c.pad; d.M = g.M; d.nmt = cdiv(g.M, 16);
+        d.H = g.H; d.W = g.W; d.Wo = g.Wo; d.Cout = c.cout; d.K = c.k;
+        d.stride = c.stride; d.M = g.M; d.nmt = cdiv(g.M, 16);
         d.ntiles = d.nmt * (c.cout / 16);
         d.relu = relu; d.relu_post = relu_post; d.has_add = has_add ? 1 : 0;
         if (ci == 0) {      // stem: channel-padded image, padded weights in the workspace
-            d.Cin = 4; d.w_off = fb(net->w4); d.w_in_ws = 1; d.S = cdiv(c.k * c.k, 4); d.cshift = 0;
+            d.Cin = 4; d.w_off = fb(net->w4); d.S = cdiv(c.k * c.k, 4); d.cshift = 0;
         } else {
-            d.Cin = c.cin; d.w_off = fb(c.w); d.w_in_ws = 0;
+            d.Cin = c.cin; d.w_off = fb(c.w);
             const int cgn = c.cin / 16;
             d.S = c.k * c.k * cgn;
             while ((1 << d.cshift) < cgn) ++d.cshift;
         }
+        d.krow4 = c.k * c.k * d.Cin * 4;
+        d.wo_magic = magic20(g.Wo, d.nmt * 16 + 16);
+        d.nmt_magic = magic20(d.nmt, d.ntiles);
         return d;
     };
     auto check_conv = [&](int ci) -> bool {
         const ConvT& c = A.convs[ci];
         const int cgn = c.cin / 16;
-        return c.cin % 16 == 0 && c.cout % 16 == 0 && c.k * c.k <= 9 && (cgn & (cgn - 1)) == 0;
+        return c.cin % 16 == 0 && c.cout % 16 == 0 && (cgn & (cgn - 1)) == 0 &&
+               ((c.k == 3 && c.pad == 1) || (c.k == 1 && c.pad == 0));
     };
+    // Shape of one stage: waves per unit (wpt), workgroups per tile (split of the reduction index,
+    // ks) and channel tiles per unit (nt) of its one or two convolutions.  All units in ONE pass of
+    // slots; a wave holds at most kB1MaxK weight fragments.  Cost = k-groups the busiest CU streams
+    // after the barrier (activation fragments; the weight fragments are in flight before it and
+    // count half; 2 KB each at ~70 GB/s per CU: 35 per microsecond) + ~50 for a ticketed combine.
+    constexpr int kB1MaxK = 8;
+    bool plan_ok = true;
     auto push_conv_stage = [&](int type, const B1Conv& c0, const B1Conv* c1) {
         B1Stage st;
         memset(&st, 0, sizeof(st));
-        st.type = type; st.nprob = c1 ? 2 : 1;
-        st.c[0] = c0;
-        if (c1) st.c[1] = *c1;
-        st.total_tiles = c0.ntiles + (c1 ? c1->ntiles : 0);
-        st.wpt = pick_wpt(st.total_tiles);
+        st.type = type;
+        struct Opt { int ks, nt; };
+        const Opt opts[5] = {{1, 1}, {2, 1}, {3, 1}, {4, 1}, {1, 2}};
+        int best_cost = 1 << 30, bw = 0, b0 = 0, b1 = 0;
+        auto units_of = [&](const B1Conv& c, const Opt& o) { return c.ntiles / o.nt * o.ks; };
+        auto feasible = [&](const B1Conv& c, const Opt& o, int w) {
+            if (o.nt == 2 && (c.Cout % 32 != 0 || type == B1_STEM)) return false;
+            if (o.ks > 1 && (type == B1_STEM || o.ks > c.S)) return false;
+            return cdiv(cdiv(c.S, o.ks), w) * o.nt <= kB1MaxK;
+        };
+        for (int w : {16, 8, 4, 2})
+            for (int i0 = 0; i0 < 5; ++i0)
+                for (int i1 = 0; i1 < (c1 ? 5 : 1); ++i1) {
+                    if (!feasible(c0, opts[i0], w) || (c1 && !feasible(*c1, opts[i1], w))) continue;
+                    const int units = units_of(c0, opts[i0]) + (c1 ? units_of(*c1, opts[i1]) : 0);
+                    if (units > nblk * (16 / w)) continue;
+                    auto load = [&](const B1Conv& c, const Opt& o) {
+                        const int sp = cdiv(c.S, o.ks);
+                        return 2 * sp + sp * o.nt;          // activations + half the weights, x2
+                    };
+                    int l = load(c0, opts[i0]);
+                    if (c1 && load(*c1, opts[i1]) > l) l = load(*c1, opts[i1]);
+                    const int cost = cdiv(units, nblk) * l / 2 +
+                                     ((opts[i0].ks > 1 || (c1 && opts[i1].ks > 1)) ? 50 : 0);
+                    if (cost < best_cost) { best_cost = cost; bw = w; b0 = i0; b1 = i1; }
+                }
+        if (bw == 0) { plan_ok = false; bw = 2; }
+        auto fin = [&](B1Conv d, const Opt& o, int ticket0, size_t slab) {
+            d.ksplit = o.ks; d.nt = o.nt;
+            d.sper = cdiv(d.S, o.ks); d.per = cdiv(d.sper, bw);
+            d.nunits = d.ntiles / o.nt * o.ks;
+            d.ks_magic = magic20(o.ks, d.nunits);
+            d.nmt_magic = magic20(d.nmt, d.ntiles);
+            d.ticket0 = ticket0;
+            d.slab_off = fb(slab);
+            if (o.ks > 1 && ticket0 + d.ntiles > kB1Tickets) plan_ok = false;
+            if (o.ks > 1 && (size_t)o.ks * d.nmt * 16 * d.Cout > net->b1_slab_floats / 2) plan_ok = false;
+            return d;
+        };
+        st.c[0] = fin(c0, opts[b0], 0, net->b1_slabs);
+        if (c1) st.c[1] = fin(*c1, opts[b1], c0.ntiles, net->b1_slabs + net->b1_slab_floats / 2);
+        st.wpt = bw;
+        st.nunits0 = st.c[0].nunits;
+        st.total_units = st.c[0].nunits + (c1 ? st.c[1].nunits : 0);
         T.push_back(st);
     };
     {   // uint8 frame -> normalised NHWC4
         B1Stage st;
         memset(&st, 0, sizeof(st));
         st.type = B1_PRE; st.pH = net->H; st.pW = net->W; st.dst_off = fb(net->x4);
+        // ... and the speed encoder, evaluated by one block beside the pixel work
+        st.h.se_w0 = fb(A.se0.w); st.h.se_b0 = fb(A.se0.b);
+        st.h.se_w1 = fb(A.se3.w); st.h.se_b1 = fb(A.se3.b);
+        st.h.y_off[0] = fb(net->s1);
         T.push_back(st);
     }
     push_conv_stage(B1_STEM, conv_desc(0, net->x4, false, 0, 1, 0), nullptr);
@@ -1463,14 +1531,12 @@ static int b1_build(cilrs_net* net, int nblk) {
         h.in[0] = A.br[0][layer].in; h.in[1] = sp.in;
         h.out[0] = A.br[0][layer].out; h.out[1] = sp.out;
         h.relu = layer < 2; h.first = layer == 0; h.last = layer == 2;
-        h.x_off[0] = fb(layer == 1 ? net->h1[0] : net->h2[0]);
+        h.x_off[0] = fb(layer == 0 ? net->s1 : layer == 1 ? net->h1[0] : net->h2[0]);
         h.x_off[1] = fb(layer == 1 ? net->p1 : net->p2);
         h.y_off[0] = fb(layer == 0 ? net->h1[0] : net->h2[0]);
         h.y_off[1] = fb(layer == 0 ? net->p1 : net->p2);
         if (layer == 0) {
             h.feat_off = fb(cur); h.featHW = net->featHW; h.featC = A.feat;
-            h.se_w0 = fb(A.se0.w); h.se_b0 = fb(A.se0.b);
-            h.se_w1 = fb(A.se3.w); h.se_b1 = fb(A.se3.b);
             CILRS_CHECK(A.feat == 512 && h.in[0] == 640 && h.in[1] == 512,
                         "infer_b1: head geometry");
         }
@@ -1478,6 +1544,10 @@ static int b1_build(cilrs_net* net, int nblk) {
                     "infer_b1: head width");
         T.push_back(st);
     }
+    CILRS_CHECK(magic_ok, "infer_b1: division constants do not cover this geometry");
+    CILRS_CHECK(plan_ok, "infer_b1: no one-pass tiling of a stage on %d workgroups", nblk);
+    CILRS_CHECK(A.convs[0].k == 7 && A.convs[0].pad == 3 && A.convs[0].stride == 2,
+                "infer_b1: stem geometry");
     CILRS_CHECK((int)T.size() <= kB1MaxStages, "infer_b1: %d stages", (int)T.size());
     return 0;
 }
@@ -1540,6 +1610,23 @@ int cilrs_net_b1_stage_us(cilrs_net* net, const cilrs_buffers* bufs, float* star
     for (int i = 0; i < n; ++i) {          // 100 MHz clock
         start_us[i] = (float)((h[i] - h[0]) * 0.01);
         work_us[i] = (float)((h[kB1MaxStages + 1 + i] - h[i]) * 0.01);
+    }
+    if (getenv("CILRS_B1_FINE")) {         // when each workgroup finished each stage (us after its start)
+        const int nb = net->b1_blocks;
+        std::vector<long long> d((size_t)n * nb);
+        CILRS_HIP(hipMemcpy(d.data(), reinterpret_cast<long long*>(reinterpret_cast<float*>(bufs->workspace) +
+                                                                  net->b1_stamps) + 10 * (kB1MaxStages + 1),
+                            d.size() * sizeof(long long), hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; ++i) {
+            std::vector<double> t(nb);
+            for (int b = 0; b < nb; ++b) t[b] = (d[(size_t)i * nb + b] - h[i]) * 0.01;
+            std::vector<double> srt = t;
+            std::sort(srt.begin(), srt.end());
+            int worst = 0;
+            for (int b = 0; b < nb; ++b) if (t[b] > t[worst]) worst = b;
+            fprintf(stderr, "stage %2d done: min %5.2f p50 %5.2f p90 %5.2f max %5.2f (block %d; block 0 %5.2f)\n",
+                    i, srt[0], srt[nb / 2], srt[nb * 9 / 10], srt[nb - 1], worst, t[0]);
+        }
     }
     if (getenv("CILRS_B1_FINE"))           // conv stages: block 0 / wave 0 inside the stage
         for (int i = 0; i < n; ++i) {
