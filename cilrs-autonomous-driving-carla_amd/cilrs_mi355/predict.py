@@ -10,8 +10,13 @@ parity-unpinned) into the same kernel: the whole of preprocess_image runs on the
 """
 from __future__ import annotations
 
+import ctypes as _C
+import os
+
 import numpy as np
 import torch
+
+from . import _lib as _L
 
 IMG_MEAN = (0.485, 0.456, 0.406)       # autonomous_drive.py:481
 IMG_STD = (0.229, 0.224, 0.225)        # :482
@@ -59,12 +64,17 @@ class Predictor:
         self.out_host = torch.empty(batch * 4, dtype=torch.float32).pin_memory()
         self.ctrl_dev = self.out_dev[:batch * 3].view(batch, 3)
         self.spd_out_dev = self.out_dev[batch * 3:]
+        self._ctrl_host = self.out_host[:batch * 3].view(batch, 3)
+        self._spd_host = self.out_host[batch * 3:]
+        # CILRS_B1_ZERO_COPY=0: stage through device buffers (A/B switch of tools/infer_b1_probe.py)
+        self.zero_copy = os.environ.get("CILRS_B1_ZERO_COPY", "1") != "0"
         self._ctrl_np = self.out_host[:batch * 3].view(batch, 3).numpy()
         self._spd_np = self.out_host[batch * 3:].numpy()
         self._frames_np = self.frames_host.numpy()
         self._speed_np = self.speed_host.numpy()
         self._cmd_np = self.cmd_host.numpy()
         self._seen_epoch = -1
+        self._fast = None
 
     def _order_after_weight_updates(self):
         # The forward runs on this predictor's own stream.  Whatever last wrote the weights (a
@@ -94,6 +104,8 @@ class Predictor:
                           self.frames_host.size(2), self.use_graph, self.half, self.persistent)
         if self.model.training:
             self.model.eval()
+        if self.persistent and self.zero_copy:
+            return self._tick_persistent(frames_u8, speeds_kmh, commands)
         # host staging through NUMPY views of the pinned buffers: torch CPU ops would wake the
         # intra-op thread pool, whose spinning workers exhaust a container's CPU quota and stall
         # the control loop for ~90 ms every ~200 ms (measured: tools/stall_probe2.py)
@@ -104,14 +116,51 @@ class Predictor:
         np.copyto(self._cmd_np, self._check_commands(commands))
         self._order_after_weight_updates()
         with torch.cuda.stream(self.stream):
-            self.in_dev.copy_(self.in_host, non_blocking=True)
-            self.eng.run_forward_u8(self.frames_dev, self.speed_dev, self.cmd_dev,
-                                    out=(self.ctrl_dev, self.spd_out_dev), graph=self.use_graph,
-                                    half=self.half, persistent=self.persistent)
-            self.out_host.copy_(self.out_dev, non_blocking=True)     # pinned; no torch kernels
-            self.stream.synchronize()
+            if self.persistent and self.zero_copy:
+                # the one launch reads the frame / speed / command straight from the pinned
+                # staging buffer and writes its four outputs into pinned host memory: no copy
+                # commands on the stream, one launch + one synchronisation per tick
+                self.eng.run_forward_u8(self.frames_host, self.speed_host, self.cmd_host,
+                                        out=(self._ctrl_host, self._spd_host), persistent=True)
+                self.stream.synchronize()
+            else:
+                self.in_dev.copy_(self.in_host, non_blocking=True)
+                self.eng.run_forward_u8(self.frames_dev, self.speed_dev, self.cmd_dev,
+                                        out=(self.ctrl_dev, self.spd_out_dev), graph=self.use_graph,
+                                        half=self.half, persistent=self.persistent)
+                self.out_host.copy_(self.out_dev, non_blocking=True)     # pinned; no torch kernels
+                self.stream.synchronize()
         if self.persistent and not np.isfinite(self._ctrl_np).all():
             self.eng.check_status()       # a grid barrier that gave up leaves NaN outputs
+        out = np.empty((self.batch, 4), dtype=np.float32)
+        out[:, :3] = self._ctrl_np
+        out[:, 3] = self._spd_np * np.float32(SPEED_NORM_FACTOR)                # :920
+        return out
+
+    def _tick_persistent(self, frames_u8, speeds_kmh, commands):
+        """One control-loop tick on the persistent launch: stage the inputs in the pinned buffer
+        (numpy), ONE library call that launches and synchronises, read the pinned outputs.  The
+        kernel reads the frame and writes its four floats in host memory itself."""
+        np.copyto(self._frames_np, frames_u8, casting="unsafe")
+        self._speed_np[...] = np.minimum(
+            np.asarray(speeds_kmh, dtype=np.float64) / SPEED_NORM_FACTOR, 1.0)
+        np.copyto(self._cmd_np, self._check_commands(commands))
+        eng = self.eng
+        fast = self._fast
+        if fast is None or self._seen_epoch != eng.weights_epoch:
+            self._order_after_weight_updates()
+            pl = eng.plan(self.batch, self.frames_host.size(1), self.frames_host.size(2))
+            eng._announce_weights(pl)
+            eng.last_plan = pl
+            L = _L
+            fast = self._fast = (L.lib().cilrs_net_forward_u8_b1_sync, pl.handle, _C.byref(pl.bufs),
+                                 L.ptr(self.frames_host), L.ptr(self.speed_host),
+                                 L.ptr(self.cmd_host), L.ptr(self._ctrl_host), L.ptr(self._spd_host),
+                                 _C.c_void_p(self.stream.cuda_stream), pl)
+        if fast[0](*fast[1:9]) != 0:
+            _L.check(1)
+        if not np.isfinite(self._ctrl_np).all():
+            eng.check_status()            # a grid barrier that gave up leaves NaN outputs
         out = np.empty((self.batch, 4), dtype=np.float32)
         out[:, :3] = self._ctrl_np
         out[:, 3] = self._spd_np * np.float32(SPEED_NORM_FACTOR)                # :920
@@ -142,11 +191,33 @@ class Predictor:
                 return (buf[:nfr].view((1,) + frame.shape), buf[o_spd:o_spd + 4].view(torch.float32),
                         buf[o_spd + 8:o_spd + 16].view(torch.int64))
             hv, dv = views(host), views(dev)
-            cam = (host, (hv[0].numpy(), hv[1].numpy(), hv[2].numpy()), (dev,) + dv, frame.shape)
+            cam = (host, (hv[0].numpy(), hv[1].numpy(), hv[2].numpy()), (dev,) + dv, frame.shape,
+                   (hv[1], hv[2]))
             self._cam = cam
         np.copyto(cam[1][0][0], frame)
         cam[1][1][...] = min(float(speed_kmh) / SPEED_NORM_FACTOR, 1.0)
         cam[1][2][...] = self._check_commands([int(command_idx)])
+        if self.persistent and self.zero_copy:
+            # the transform kernel samples the pinned camera frame in place (it touches a fraction
+            # of its 1.9 MB), the persistent launch starts at its second stage; one library call
+            eng = self.eng
+            if self._seen_epoch != eng.weights_epoch or self._fast is None:
+                self._order_after_weight_updates()
+                pl = eng.plan(1, self.frames_host.size(1), self.frames_host.size(2))
+                eng._announce_weights(pl)
+                self._fast = None
+            pl = eng.plan(1, self.frames_host.size(1), self.frames_host.size(2))
+            eng.last_plan = pl
+            hs, ws_, px = frame.shape
+            _L.check(_L.lib().cilrs_net_forward_camera_b1(
+                pl.handle, _C.byref(pl.bufs), _L.ptr(cam[0]), hs, ws_, px, ws_ * px,
+                _L.ptr(cam[4][0]), _L.ptr(cam[4][1]), _L.ptr(self._ctrl_host),
+                _L.ptr(self._spd_host), 1, _C.c_void_p(self.stream.cuda_stream)))
+            if not np.isfinite(self._ctrl_np).all():
+                eng.check_status()
+            c = self._ctrl_np[0]
+            return (float(c[0]), float(c[1]), float(c[2]),
+                    float(self._spd_np[0]) * SPEED_NORM_FACTOR)
         self._order_after_weight_updates()
         with torch.cuda.stream(self.stream):
             cam[2][0].copy_(cam[0], non_blocking=True)               # frame | speed | command

@@ -318,7 +318,9 @@ struct B1Stage {
     B1Conv c[2];
     B1Head h;
     unsigned src_off, dst_off; int pH, pW, pC, pHo, pWo;    // B1_PRE / B1_POOL geometry
-    int pad_[1];
+    unsigned cmd_off;        // where stage 0 parks the command for the head stages (ws bytes)
+    int same_shape;          // conv stage laid out exactly like the previous one (only bases differ)
+    int pad_[3];
 };
 constexpr int kB1MaxStages = 48;
 constexpr int kB1Tickets = 512;            // split-K arrival tickets (one per output tile of a stage)
@@ -326,6 +328,7 @@ constexpr int kB1SyncInts = 9 * 32 + kB1Tickets;   // 8 counter shards + the epo
                                                    // line each), then the tickets
 struct B1Launch {
     const B1Stage* table; int nstages;     // device table
+    int first_stage;                       // 0; 1 = the normalised NHWC4 image is already in place
     float* ws; size_t ws_bytes;
     const float* params; size_t param_bytes;
     const unsigned char* frame; const float* speed; const long long* cmd;

@@ -57,17 +57,20 @@ static_assert(sizeof(B1Stage) % 16 == 0, "B1Stage must stay 16-byte granular");
 
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 
-__device__ __forceinline__ f32x4 ld_act(const rsrc_t rs, const unsigned off) {      // handed-off bytes
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 16));
+// (`base`: wave-uniform byte offset, added by the hardware; it takes no part in the range check, so
+//  a lane offset of 0xFFFFFFFF still reads zeros)
+__device__ __forceinline__ f32x4 ld_act(const rsrc_t rs, const unsigned off, const unsigned base = 0u) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, (int)base, 16));
 }
-__device__ __forceinline__ f32x4 ld_const(const rsrc_t rs, const unsigned off) {    // earlier launches
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
+__device__ __forceinline__ f32x4 ld_const(const rsrc_t rs, const unsigned off, const unsigned base = 0u) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, (int)base, 0));
 }
 __device__ __forceinline__ float ld_const1(const rsrc_t rs, const unsigned off) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0));
 }
-__device__ __forceinline__ void st_act(const rsrc_t rs, const unsigned off, const f32x4 v) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (int)off, 0, 16);
+__device__ __forceinline__ void st_act(const rsrc_t rs, const unsigned off, const f32x4 v,
+                                       const unsigned base = 0u) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (int)off, (int)base, 16);
 }
 __device__ __forceinline__ void st_act1(const rsrc_t rs, const unsigned off, const float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, (int)off, 0, 16);
@@ -133,58 +136,120 @@ __device__ __forceinline__ void grid_wait(int* sync, const int target, volatile 
 // One wave's share of a convolution stage: everything that can be known before the stage's inputs
 // exist.  Scalars are wave-uniform.  A unit is a 16-row x (16 * nt)-channel output tile (nt = 1 or
 // 2: two channel tiles share every activation fragment) times one slice of the reduction index.
+// Lane offsets are RELATIVE to the tensors' bases, which ride in the buffer instructions' scalar
+// offset: consecutive stages of one shape (the second .. last convolution of a ResNet layer) keep
+// the lane part of the plan and only refresh the bases (plan_rebase).
 struct ConvPlan {
     int active, wig, grp, wpt, nk, nt;     // unit assigned?  wave in group, group, waves per unit,
                                            // k-groups of this wave, channel tiles per unit
     int ksplit, kj, ticket;                // workgroups per tile, this one's slice, ticket word
     int relu, relu_post, has_add;
-    int sb, krow4;                         // first k-group of this wave; weight row pitch (bytes)
-    unsigned wOff;                         // this lane's weight row (bytes)
-    unsigned offA[kSU];                    // activation fragment offsets (0xFFFFFFFF: zeros)
-    f32x4 b[kSU];                          // weight fragments, [k-group][channel tile]
-    unsigned e_bn, e_bn_shift;             // folded BatchNorm of the epilogue wave's four channels
-    unsigned e_yoff, e_addoff, e_slab, e_slab_pitch;
+    unsigned x_off, w_off, w_off1, y_off, add_off, scale_off, shift_off, slab_off;   // bases (bytes)
+    int sb, pi;                            // first k-group of this wave; sub-problem of the stage
+    unsigned wrel;                         // this lane's weight row + first k-group (relative)
+    unsigned offA[kSU];                    // activation fragment offsets (relative; ~0: zeros)
+    unsigned e_rel, e_bn_rel, e_slab_pitch;   // epilogue wave: output element / channel (relative)
     int e_store;
 };
 
 __device__ __forceinline__ void plan_clear(ConvPlan& p) {
     p.active = 0; p.wig = 0; p.grp = 0; p.wpt = 16; p.nk = 0; p.nt = 1;
     p.ksplit = 1; p.kj = 0; p.ticket = 0; p.relu = 0; p.relu_post = 0; p.has_add = 0;
-    p.e_store = 0; p.e_yoff = 0u; p.e_addoff = 0xFFFFFFFFu; p.e_slab = 0u; p.e_slab_pitch = 0u;
-    p.e_bn = 0u; p.e_bn_shift = 0u; p.sb = 0; p.krow4 = 0; p.wOff = 0u;
+    p.x_off = p.w_off = p.w_off1 = p.y_off = p.add_off = p.scale_off = p.shift_off = p.slab_off = 0u;
+    p.sb = 0; p.pi = 0; p.wrel = 0u; p.e_rel = 0u; p.e_bn_rel = 0u; p.e_slab_pitch = 0u; p.e_store = 0;
 #pragma unroll
-    for (int u = 0; u < kSU; ++u) { p.offA[u] = 0xFFFFFFFFu; p.b[u] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int u = 0; u < kSU; ++u) p.offA[u] = 0xFFFFFFFFu;
 }
 
 // The weight fragments of a plan: slot of (k-group u, channel tile j) = u * nt + j (host: nk * nt
 // <= kSU).  OHWI weights: reduction index tap * Cin + 16 cg = 16 s, i.e. 64 s bytes into the row.
+struct ConvW { f32x4 b[kSU]; };          // weight fragments, [k-group][channel tile]; one stage
+
 template <int MODE>
-__device__ __forceinline__ void plan_issue_b(ConvPlan& p, const rsrc_t rsW, const rsrc_t rsP) {
+__device__ __forceinline__ void plan_issue_b(const ConvPlan& p, ConvW& cw, const rsrc_t rsW,
+                                             const rsrc_t rsP) {
     const rsrc_t rsB = MODE == 1 ? rsW : rsP;
     const int kq = (threadIdx.x & 63) >> 4;
+    const int n = RFL(p.nk) * RFL(p.nt), two = RFL(p.nt) == 2;
+    const unsigned w0 = (unsigned)RFL(p.w_off), w1 = (unsigned)RFL(p.w_off1);
 #pragma unroll
     for (int i = 0; i < kSU; ++i) {
-        if (i < p.nk * p.nt) {
-            const int u = p.nt == 2 ? (i >> 1) : i, j = p.nt == 2 ? (i & 1) : 0;
-            const int s = p.sb + u;
-            unsigned offB;
-            if (MODE == 0) {
-                offB = p.wOff + (unsigned)(s * 64) + (unsigned)(j * 16 * p.krow4);
-            } else {
-                const int tap = 4 * s + kq;
-                offB = tap < 49 ? p.wOff + (unsigned)(tap * 16) : 0xFFFFFFFFu;
-            }
-            p.b[i] = ld_const(rsB, offB);
+        if (i < n) {
+            const int u = two ? (i >> 1) : i;
+            const unsigned base = (two && (i & 1)) ? w1 : w0;
+            unsigned off = p.wrel + (unsigned)(u * 64);
+            if (MODE == 1 && 4 * (RFL(p.sb) + u) + kq >= 49) off = 0xFFFFFFFFu;
+            cw.b[i] = ld_const(rsB, off, base);
         }
     }
 }
 
-// defer_b: the wave loads its weight fragments later (plan_issue_b): the
-// polling wave after its poll (a poll is an in-order vector load and would otherwise wait behind
-// them), an epilogue wave after the drain of its stores.
+// the bases of a stage and what its epilogue does: all that changes between stages of one shape
+__device__ __forceinline__ void plan_bases(ConvPlan& p, const B1Conv* c) {
+    const i32x4* cv = reinterpret_cast<const i32x4*>(c);
+    const i32x4 q0 = cv[0], q1 = cv[1], q4 = cv[4], q5 = cv[5], q7 = cv[7];
+    p.x_off = (unsigned)RFL(q0[0]); p.y_off = (unsigned)RFL(q0[1]);
+    p.add_off = (unsigned)RFL(q0[2]); p.w_off = (unsigned)RFL(q0[3]);
+    p.scale_off = (unsigned)RFL(q1[0]); p.shift_off = (unsigned)RFL(q1[1]);
+    p.w_off1 = p.w_off + (unsigned)(16 * RFL(q4[2]));          // second channel tile: 16 rows on
+    p.relu = RFL(q4[3]); p.relu_post = RFL(q5[0]); p.has_add = RFL(q5[1]);
+    p.slab_off = (unsigned)RFL(q7[0]);
+}
+
+// The shape part of a plan parks in LDS between stages (registers stay free for the stage bodies):
+// lane words as [word][thread] (conflict-free), wave scalars as [wave][16].
+constexpr int kPlanLaneWords = kSU + 5;
+__device__ __forceinline__ void plan_save(const ConvPlan& p, unsigned* lds_lane, int* lds_wave) {
+    const int tid = threadIdx.x, wave = RFL(tid >> 6);
+#pragma unroll
+    for (int u = 0; u < kSU; ++u) lds_lane[u * kThreads + tid] = p.offA[u];
+    lds_lane[(kSU + 0) * kThreads + tid] = p.wrel;
+    lds_lane[(kSU + 1) * kThreads + tid] = p.e_rel;
+    lds_lane[(kSU + 2) * kThreads + tid] = p.e_bn_rel;
+    lds_lane[(kSU + 3) * kThreads + tid] = p.e_slab_pitch;
+    lds_lane[(kSU + 4) * kThreads + tid] = (unsigned)p.e_store;
+    if ((tid & 63) == 0) {
+        int* w = lds_wave + wave * 16;
+        w[0] = p.active; w[1] = p.wig; w[2] = p.grp; w[3] = p.wpt; w[4] = p.nk; w[5] = p.nt;
+        w[6] = p.ksplit; w[7] = p.kj; w[8] = p.ticket; w[9] = p.sb; w[10] = p.pi;
+    }
+}
+__device__ __forceinline__ void plan_load(ConvPlan& p, const unsigned* lds_lane, const int* lds_wave) {
+    const int tid = threadIdx.x, wave = RFL(tid >> 6);
+    const i32x4* w = reinterpret_cast<const i32x4*>(lds_wave + wave * 16);
+    const i32x4 w0 = w[0], w1 = w[1], w2 = w[2];
+    plan_clear(p);
+    p.active = RFL(w0[0]); p.wig = RFL(w0[1]); p.grp = RFL(w0[2]); p.wpt = RFL(w0[3]);
+    p.nk = RFL(w1[0]); p.nt = RFL(w1[1]); p.ksplit = RFL(w1[2]); p.kj = RFL(w1[3]);
+    p.ticket = RFL(w2[0]); p.sb = RFL(w2[1]); p.pi = RFL(w2[2]);
+    if (!p.active) return;
+#pragma unroll
+    for (int u = 0; u < kSU; ++u) p.offA[u] = lds_lane[u * kThreads + tid];
+    p.wrel = lds_lane[(kSU + 0) * kThreads + tid];
+    p.e_rel = lds_lane[(kSU + 1) * kThreads + tid];
+    p.e_bn_rel = lds_lane[(kSU + 2) * kThreads + tid];
+    p.e_slab_pitch = lds_lane[(kSU + 3) * kThreads + tid];
+    p.e_store = (int)lds_lane[(kSU + 4) * kThreads + tid];
+}
+
+// Same shape as the previous stage (host flag): take the parked lane part, refresh the bases, put
+// the weight fragments in flight.
 template <int MODE>
-__device__ __forceinline__ void plan_conv(ConvPlan& p, const B1Stage* st, const rsrc_t rsW,
-                                          const rsrc_t rsP, const int nblk, const bool defer_b) {
+__device__ __forceinline__ void plan_rebase(ConvPlan& p, ConvW& cw, const B1Stage* st,
+                                            const rsrc_t rsW, const rsrc_t rsP, const bool defer_b,
+                                            const unsigned* lds_lane, const int* lds_wave) {
+    plan_load(p, lds_lane, lds_wave);
+    if (!RFL(p.active)) return;
+    plan_bases(p, &st->c[RFL(p.pi)]);
+    if (!defer_b) plan_issue_b<MODE>(p, cw, rsW, rsP);
+}
+
+// defer_b: the wave loads its weight fragments later (plan_issue_b): the polling wave after its
+// poll (a poll is an in-order vector load and would otherwise wait behind them).
+template <int MODE>
+__device__ __forceinline__ void plan_conv(ConvPlan& p, ConvW& cw, const B1Stage* st,
+                                          const rsrc_t rsW, const rsrc_t rsP, const int nblk,
+                                          const bool defer_b) {
     const int lane = threadIdx.x & 63, wave = RFL(threadIdx.x >> 6);
     const int r = lane & 15, kq = lane >> 4;
     const i32x4 hd = *reinterpret_cast<const i32x4*>(st);           // type, wpt, nunits0, total
@@ -205,13 +270,10 @@ __device__ __forceinline__ void plan_conv(ConvPlan& p, const B1Stage* st, const 
     if (!p.active) return;
     const int pi = t >= nunits0 ? 1 : 0;
     if (pi) t -= nunits0;
-    // the whole descriptor in eight LDS reads, then scalars
+    p.pi = pi;
+    plan_bases(p, &st->c[pi]);
     const i32x4* cv = reinterpret_cast<const i32x4*>(&st->c[pi]);
-    const i32x4 q0 = cv[0], q1 = cv[1], q2 = cv[2], q3 = cv[3], q4 = cv[4], q5 = cv[5], q6 = cv[6],
-                q7 = cv[7];
-    const unsigned x_off = (unsigned)RFL(q0[0]), y_off = (unsigned)RFL(q0[1]);
-    const unsigned add_off = (unsigned)RFL(q0[2]), w_off = (unsigned)RFL(q0[3]);
-    const unsigned scale_off = (unsigned)RFL(q1[0]), shift_off = (unsigned)RFL(q1[1]);
+    const i32x4 q1 = cv[1], q2 = cv[2], q3 = cv[3], q4 = cv[4], q5 = cv[5], q6 = cv[6], q7 = cv[7];
     const int H = RFL(q1[2]), W = RFL(q1[3]);
     const int Cin = RFL(q2[0]), Wo = RFL(q2[1]), Cout = RFL(q2[2]), K = RFL(q2[3]);
     const int stride = RFL(q3[0]), M = RFL(q3[1]), nmt = RFL(q3[2]);
@@ -220,7 +282,7 @@ __device__ __forceinline__ void plan_conv(ConvPlan& p, const B1Stage* st, const 
     const int ksplit = RFL(q6[0]), sper = RFL(q6[1]), per = RFL(q6[2]);
     const unsigned ks_magic = (unsigned)RFL(q6[3]);
     const int nt = RFL(q7[3]);
-    p.relu = RFL(q4[3]); p.relu_post = RFL(q5[0]); p.has_add = RFL(q5[1]); p.nt = nt;
+    p.nt = nt;
     // unit -> (tile, k-slice); tile -> (channel tile, row tile), rows fastest
     const int tile = (int)(((unsigned)t * ks_magic) >> 20), kj = t - tile * ksplit;
     const int ntile = (int)(((unsigned)tile * nmt_magic) >> 20), mt = tile - ntile * nmt;
@@ -230,9 +292,10 @@ __device__ __forceinline__ void plan_conv(ConvPlan& p, const B1Stage* st, const 
     const int ub = kj * sper, ue = min(S, ub + sper);
     const int sb = ub + wig * per, se = min(ue, sb + per);
     p.nk = max(se - sb, 0);
+    p.sb = sb;
     const int m = m0 + r;
     const int oh = (int)(((unsigned)m * wo_magic) >> 20), ow = m - oh * Wo;
-    unsigned rowOff = 0u, rowMask = 0u, wOff = 0u;
+    unsigned rowOff = 0u, rowMask = 0u;
     int tapA_v = 0, hb = 0, wb = 0;
     if (MODE == 0) {
         if (K == 3) {          // pad 1: tap (kh, kw) is inside iff 0 <= hb + kh < H, same for w
@@ -247,10 +310,11 @@ __device__ __forceinline__ void plan_conv(ConvPlan& p, const B1Stage* st, const 
             rowMask = 1u;
         }
         if (m >= M) rowMask = 0u;
-        rowOff = x_off + (unsigned)(((hb * W + wb) * Cin + kq * 4) * 4);
-        wOff = w_off + (unsigned)((n0 + r) * krow4 + kq * 16);
+        rowOff = (unsigned)(((hb * W + wb) * Cin + kq * 4) * 4);
+        p.wrel = (unsigned)((n0 + r) * krow4 + kq * 16 + sb * 64);
     } else {
         hb = oh * 2 - 3; wb = ow * 2 - 3;
+        p.wrel = (unsigned)(((n0 + r) * 49 + 4 * sb + kq) * 16);
     }
 #pragma unroll
     for (int u = 0; u < kSU; ++u) {
@@ -267,24 +331,18 @@ __device__ __forceinline__ void plan_conv(ConvPlan& p, const B1Stage* st, const 
                 const int kh = (tap * 37) >> 8, kw = tap - 7 * kh;       // tap / 7, tap < 56
                 const int h = hb + kh, w = wb + kw;
                 const bool ok = tap < 49 && m < M && h >= 0 && w >= 0 && h < H && w < W;
-                p.offA[u] = ok ? x_off + (unsigned)((h * W + w) * 16) : 0xFFFFFFFFu;
+                p.offA[u] = ok ? (unsigned)((h * W + w) * 16) : 0xFFFFFFFFu;
             }
         }
     }
-    p.sb = sb; p.krow4 = krow4;
-    p.wOff = MODE == 0 ? wOff : w_off + (unsigned)((n0 + r) * 49 * 16);
-    if (!defer_b) plan_issue_b<MODE>(p, rsW, rsP);
-    if (wig == 0) {          // the unit's epilogue wave: output / residual / slab addresses, BatchNorm
+    if (!defer_b) plan_issue_b<MODE>(p, cw, rsW, rsP);
+    if (wig == 0) {          // the unit's epilogue wave: output element / channel of this lane
         const int row = lane >> 2, c4 = (lane & 3) * 4;
         const int me = m0 + row;
         p.e_store = me < M;
-        const unsigned eo = (unsigned)((me * Cout + n0 + c4) * 4);
-        p.e_yoff = y_off + eo;
-        p.e_addoff = (p.has_add && p.e_store) ? add_off + eo : 0xFFFFFFFFu;
+        p.e_rel = (unsigned)((me * Cout + n0 + c4) * 4);
         p.e_slab_pitch = (unsigned)(nmt * 16 * Cout * 4);
-        p.e_slab = (unsigned)RFL(q7[0]) + eo;
-        p.e_bn = scale_off + (unsigned)((n0 + c4) * 4);
-        p.e_bn_shift = shift_off - scale_off;
+        p.e_bn_rel = (unsigned)((n0 + c4) * 4);
     }
 }
 
@@ -309,23 +367,24 @@ __device__ __forceinline__ f32x4 sum_partials(const float* rp) {
 struct ConvEpi { f32x4 add0, add1, sc0, sc1, sh0, sh1; };
 
 // Multiply phase (every wave): activation loads, MFMAs, partial tiles to LDS [wave][nt][16][16].
-__device__ __forceinline__ void exec_conv_main(const ConvPlan& p, ConvEpi& ep, const rsrc_t rsW,
-                                               float* red, long long* fine) {
+__device__ __forceinline__ void exec_conv_main(const ConvPlan& p, const ConvW& cw, ConvEpi& ep,
+                                               const rsrc_t rsW, float* red, long long* fine) {
     const int lane = threadIdx.x & 63, wave = RFL(threadIdx.x >> 6);
     const int r = lane & 15, kq = lane >> 4;
     ep.add0 = ep.add1 = ep.sh0 = ep.sh1 = f32x4{0.f, 0.f, 0.f, 0.f};
     ep.sc0 = ep.sc1 = f32x4{1.f, 1.f, 1.f, 1.f};
     B1_FINE(0);
     const int nk = RFL(p.nk), nt = RFL(p.nt), wig = RFL(p.wig), has_add = RFL(p.has_add);
+    const unsigned x_off = (unsigned)RFL(p.x_off), add_off = (unsigned)RFL(p.add_off);
     if (RFL(p.active)) {
         f32x4 av[kSU];
 #pragma unroll
         for (int u = 0; u < kSU; ++u)
-            if (u < nk) av[u] = ld_act(rsW, p.offA[u]);
+            if (u < nk) av[u] = ld_act(rsW, p.offA[u], x_off);
         if (wig == 0 && has_add) {
-            ep.add0 = ld_act(rsW, p.e_addoff);
-            if (nt == 2)
-                ep.add1 = ld_act(rsW, p.e_addoff == 0xFFFFFFFFu ? 0xFFFFFFFFu : p.e_addoff + 64u);
+            const unsigned ao = p.e_store ? p.e_rel : 0xFFFFFFFFu;
+            ep.add0 = ld_act(rsW, ao, add_off);
+            if (nt == 2) ep.add1 = ld_act(rsW, ao, add_off + 64u);
         }
         __builtin_amdgcn_sched_barrier(0);        // every load in flight before the first MFMA
         B1_FINE(1);
@@ -337,9 +396,9 @@ __device__ __forceinline__ void exec_conv_main(const ConvPlan& p, ConvEpi& ep, c
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         if (u & 1)
-                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][e], p.b[u][e], acc1, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][e], cw.b[u][e], acc1, 0, 0, 0);
                         else
-                            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][e], p.b[u][e], acc0, 0, 0, 0);
+                            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][e], cw.b[u][e], acc0, 0, 0, 0);
                     }
                 }
             }
@@ -350,19 +409,20 @@ __device__ __forceinline__ void exec_conv_main(const ConvPlan& p, ConvEpi& ep, c
                 if (u < nk) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][e], p.b[2 * u][e], acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][e], p.b[2 * u + 1][e], acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][e], cw.b[2 * u][e], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][e], cw.b[2 * u + 1][e], acc1, 0, 0, 0);
                     }
                 }
             }
         }
         B1_FINE(2);
         if (wig == 0) {          // folded BatchNorm: lands under the LDS hand-over
-            ep.sc0 = ld_const(rsW, p.e_bn);
-            ep.sh0 = ld_const(rsW, p.e_bn + p.e_bn_shift);
+            const unsigned sc = (unsigned)RFL(p.scale_off), sh = (unsigned)RFL(p.shift_off);
+            ep.sc0 = ld_const(rsW, p.e_bn_rel, sc);
+            ep.sh0 = ld_const(rsW, p.e_bn_rel, sh);
             if (nt == 2) {
-                ep.sc1 = ld_const(rsW, p.e_bn + 64u);
-                ep.sh1 = ld_const(rsW, p.e_bn + p.e_bn_shift + 64u);
+                ep.sc1 = ld_const(rsW, p.e_bn_rel, sc + 64u);
+                ep.sh1 = ld_const(rsW, p.e_bn_rel, sh + 64u);
             }
         }
         // C/D map of 16x16x4: col = lane & 15, row = 4 * (lane >> 4) + i
@@ -387,6 +447,7 @@ __device__ __forceinline__ bool exec_conv_epilogue(const ConvPlan& p, const Conv
     const int row = lane >> 2, c4 = (lane & 3) * 4;
     const int nt = RFL(p.nt), wpt = RFL(p.wpt), grp = RFL(p.grp), ksplit = RFL(p.ksplit);
     const int kj = RFL(p.kj), ticket = RFL(p.ticket), relu = RFL(p.relu), relu_post = RFL(p.relu_post);
+    const unsigned y_off = (unsigned)RFL(p.y_off), slab_off = (unsigned)RFL(p.slab_off);
     bool stored = false;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -397,7 +458,7 @@ __device__ __forceinline__ bool exec_conv_epilogue(const ConvPlan& p, const Conv
             bool finish = true;
             if (j == 0 && ksplit > 1) {      // (host: split units have one channel tile)
                 // park the partial tile, take a ticket; the last arriver sums the slices in order
-                if (p.e_store) st_act(rsW, p.e_slab + (unsigned)kj * p.e_slab_pitch, v);
+                if (p.e_store) st_act(rsW, p.e_rel + (unsigned)kj * p.e_slab_pitch, v, slab_off);
                 drain_stores();
                 int old = 0;
                 if (lane == 0)
@@ -413,7 +474,8 @@ __device__ __forceinline__ bool exec_conv_epilogue(const ConvPlan& p, const Conv
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
                         sl[k] = ld_act(rsW, (k < ksplit && p.e_store)
-                                                ? p.e_slab + (unsigned)k * p.e_slab_pitch : 0xFFFFFFFFu);
+                                                ? p.e_rel + (unsigned)k * p.e_slab_pitch : 0xFFFFFFFFu,
+                                       slab_off);
                     v = sl[0];
 #pragma unroll
                     for (int k = 1; k < 4; ++k)
@@ -431,7 +493,7 @@ __device__ __forceinline__ bool exec_conv_epilogue(const ConvPlan& p, const Conv
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
                 }
-                if (p.e_store) st_act(rsW, p.e_yoff + 64u * j, v);
+                if (p.e_store) st_act(rsW, p.e_rel, v, y_off + 64u * j);
                 stored = true;
             }
         }
@@ -543,15 +605,16 @@ __device__ __forceinline__ void head_stage(const B1Stage* st, const B1Launch& a,
                                            const rsrc_t rsP, float* hx, const int nblk) {
     const B1Head* h = &st->h;
     const int tid = threadIdx.x, lane = tid & 63, wave = RFL(tid >> 6);
-    const long long cmd = a.cmd[0];
-    const int k = (cmd < 0 || cmd > 3) ? 0 : (int)cmd;
+    const int cmd = RFL(__builtin_bit_cast(int, __builtin_amdgcn_raw_buffer_load_b32(
+        rsW, (int)(unsigned)RFL(st->cmd_off), 0, 16)));            // parked by stage 0; -1: out of range
+    const int k = cmd < 0 ? 0 : cmd;
     const int first = RFL(h->first), last = RFL(h->last);
     const int in0 = RFL(h->in[0]), in1 = RFL(h->in[1]);
     float* x0 = hx;
     float* x1 = hx + 640;
     if (first) {
         // a command outside 0..3: torch.gather would raise (:397-398); the host reads this word
-        if (blockIdx.x == 0 && tid == 0) a.status[0] = (cmd < 0 || cmd > 3) ? 1 : 0;
+        if (blockIdx.x == 0 && tid == 0) a.status[0] = cmd < 0 ? 1 : 0;
         const int HW = RFL(h->featHW), C = RFL(h->featC);
         const unsigned fo = (unsigned)RFL(h->feat_off);
         if (tid < (C >> 2)) {              // AdaptiveAvgPool2d(1,1) + Flatten (:369); pixel order
@@ -628,6 +691,7 @@ __device__ __forceinline__ void head_stage(const B1Stage* st, const B1Launch& a,
     if (stored) drain_stores();
 }
 
+__device__ __forceinline__ unsigned desc_stage_cmd_off(const B1Stage* table) { return table[0].cmd_off; }
 __device__ __forceinline__ const B1Stage* desc_stage(const int* desc, const int s) {
     return reinterpret_cast<const B1Stage*>(desc + s * kDescInts);
 }
@@ -637,6 +701,8 @@ __global__ __launch_bounds__(kThreads) void infer_b1_kernel(const B1Launch a) {
     __shared__ __attribute__((aligned(16))) float red[16 * 512];
     __shared__ __attribute__((aligned(16))) float hx[2 * 640];
     __shared__ float s1[128];
+    __shared__ unsigned plan_lane[kPlanLaneWords * kThreads];
+    __shared__ __attribute__((aligned(16))) int plan_wave[16 * 16];
     __shared__ int fail;
     const int tid = threadIdx.x;
     const int nblk = gridDim.x;
@@ -657,27 +723,49 @@ __global__ __launch_bounds__(kThreads) void infer_b1_kernel(const B1Launch a) {
         if (blockIdx.x == 0)     // a give-up (>= 1 s of polling) cannot race this store
             __hip_atomic_store(a.status + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    // the command may live in pinned HOST memory (zero-copy control loop): read it once, here, and
+    // park it next to the activations -- the three head stages then do not cross PCIe
+    if (blockIdx.x == 0 && tid == 0) {
+        const long long c = a.cmd[0];
+        st_act1(rsW, (unsigned)desc_stage_cmd_off(a.table),
+                __builtin_bit_cast(float, (c < 0 || c > 3) ? -1 : (int)c));
+        drain_stores();
+    }
     __syncthreads();
     const int per_shard = nblk >> 3;
+    const int first = a.first_stage;
     const bool poller = RFL(tid >> 6) == 0;            // wave 0 (a scalar: no divergent plans)
-    for (int s = 0; s < nstages; ++s) {
+    for (int s = first; s < nstages; ++s) {
         const B1Stage* st = desc_stage(desc, s);
         const int type = RFL(st->type);
         int failed = RFL(*reinterpret_cast<volatile int*>(&fail));     // wave-uniform
         // The plan of this stage (addresses, weight fragments in flight) is made between this
         // workgroup's arrival at the barrier (end of the previous iteration) and its wait: while
-        // the slowest workgroup is still on its way.  It lives inside one iteration.
+        // the slowest workgroup is still on its way.
+        const bool defer = poller && s > first;
         ConvPlan plan;
-        const bool defer = poller && s > 0;
-        if (!failed && type == B1_CONV) plan_conv<0>(plan, st, rsW, rsP, nblk, defer);
-        else if (!failed && type == B1_STEM) plan_conv<1>(plan, st, rsW, rsP, nblk, defer);
-        else plan_clear(plan);
-        if (s > 0) {
-            grid_wait(a.sync, base + s * per_shard, &fail, a.status);
+        ConvW cw;
+#pragma unroll
+        for (int u = 0; u < kSU; ++u) cw.b[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!failed && type == B1_CONV) {
+            if (RFL(st->same_shape)) {
+                plan_rebase<0>(plan, cw, st, rsW, rsP, defer, plan_lane, plan_wave);
+            } else {
+                plan_conv<0>(plan, cw, st, rsW, rsP, nblk, defer);
+                if (s + 1 < nstages && RFL(desc_stage(desc, s + 1)->same_shape))
+                    plan_save(plan, plan_lane, plan_wave);     // (each wave reads back its own words)
+            }
+        } else if (!failed && type == B1_STEM) {
+            plan_conv<1>(plan, cw, st, rsW, rsP, nblk, defer);
+        } else {
+            plan_clear(plan);
+        }
+        if (s > first) {
+            grid_wait(a.sync, base + (s - first) * per_shard, &fail, a.status);
             failed = RFL(*reinterpret_cast<volatile int*>(&fail));
             if (defer && !failed) {
-                if (type == B1_CONV) plan_issue_b<0>(plan, rsW, rsP);
-                else if (type == B1_STEM) plan_issue_b<1>(plan, rsW, rsP);
+                if (type == B1_CONV) plan_issue_b<0>(plan, cw, rsW, rsP);
+                else if (type == B1_STEM) plan_issue_b<1>(plan, cw, rsW, rsP);
             }
         }
         if (a.stamps && blockIdx.x == 0 && tid == 0) a.stamps[s] = __builtin_amdgcn_s_memrealtime();
@@ -685,7 +773,7 @@ __global__ __launch_bounds__(kThreads) void infer_b1_kernel(const B1Launch a) {
                               ? a.stamps + 2 * (kB1MaxStages + 1) + 8 * s : nullptr;
         if (!failed && (type == B1_CONV || type == B1_STEM)) {
             ConvEpi ep;
-            exec_conv_main(plan, ep, rsW, red, fine);
+            exec_conv_main(plan, cw, ep, rsW, red, fine);
             if (RFL(plan.active) && RFL(plan.wig) == 0) {
                 if (exec_conv_epilogue(plan, ep, rsW, red, a.sync, fine)) drain_stores();
             }
@@ -700,11 +788,12 @@ __global__ __launch_bounds__(kThreads) void infer_b1_kernel(const B1Launch a) {
             a.stamps[10 * (kB1MaxStages + 1) + s * nblk + blockIdx.x] = __builtin_amdgcn_s_memrealtime();
         if (s + 1 < nstages) {
             grid_arrive(a.sync);
-            if (s == 0 && (int)blockIdx.x == nblk - 1) speed_encoder(st, a, rsW, rsP, s1);
+            if (s == first && (int)blockIdx.x == nblk - 1)
+                speed_encoder(desc_stage(desc, 0), a, rsW, rsP, s1);
         }
     }
     if (blockIdx.x == 0 && tid == 0) {
-        __hip_atomic_store(a.sync + 8 * 32, base + (nstages - 1) * per_shard, __ATOMIC_RELAXED,
+        __hip_atomic_store(a.sync + 8 * 32, base + (nstages - 1 - first) * per_shard, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
         if (*reinterpret_cast<volatile int*>(&fail)) {
             const float nan = __builtin_nanf("");
@@ -731,7 +820,8 @@ int infer_b1_grid(int* blocks) {
 
 int launch_infer_b1(const B1Launch& a, int blocks, hipStream_t s) {
     CILRS_CHECK(blocks >= 8 && blocks % 8 == 0, "infer_b1: grid %d is not a multiple of 8", blocks);
-    CILRS_CHECK(a.nstages >= 2 && a.nstages <= kB1MaxStages, "infer_b1: bad stage count");
+    CILRS_CHECK(a.nstages >= 2 && a.nstages <= kB1MaxStages && (a.first_stage == 0 || a.first_stage == 1),
+                "infer_b1: bad stage count");
     CILRS_CHECK(a.ws_bytes < (1ull << 32) && a.param_bytes < (1ull << 32),
                 "infer_b1: arenas must be addressable with 32-bit offsets");
     infer_b1_kernel<<<blocks, kThreads, 0, s>>>(a);

@@ -310,7 +310,7 @@ struct cilrs_net {
     TransposeF16Table tr_table;
     // persistent single-frame kernel (infer_b1.hip): stage table + barrier counters in the
     // workspace (offsets in floats; 0 = this plan has none), uploaded once per workspace
-    size_t b1_table = 0, b1_sync = 0, b1_stamps = 0, b1_slabs = 0, b1_slab_floats = 0;
+    size_t b1_table = 0, b1_sync = 0, b1_stamps = 0, b1_slabs = 0, b1_slab_floats = 0, b1_cmd = 0;
     std::vector<B1Stage> b1_host;
     int b1_blocks = -1;                    // resident grid (one workgroup per CU); -1 = not asked yet
     const void* b1_ready_for = nullptr;
@@ -863,6 +863,7 @@ int cilrs_net_create_ex(int variant, int batch, int height, int width, unsigned 
     if (batch == 1 && variant == 0) {
         n->b1_table = bump.take(kB1MaxStages * sizeof(B1Stage) / sizeof(float));
         n->b1_sync = bump.take(kB1SyncInts);
+        n->b1_cmd = bump.take(16);
         n->b1_stamps = bump.take(2 * (10 * (kB1MaxStages + 1) + kB1MaxStages * 512));
         // split-K partial tiles: up to 4 slices of the largest [16-row tiles][Cout] output, twice
         // (a stage may hold two convolutions)
@@ -1477,6 +1478,20 @@ static int b1_build(cilrs_net* net, int nblk) {
         st.wpt = bw;
         st.nunits0 = st.c[0].nunits;
         st.total_units = st.c[0].nunits + (c1 ? st.c[1].nunits : 0);
+        // same lane-level plan as the previous stage?  (everything but the tensor bases, the
+        // epilogue flags and the BatchNorm tables equal)
+        if (!T.empty() && T.back().type == B1_CONV && type == B1_CONV && !c1 &&
+            T.back().total_units == T.back().nunits0 && T.back().wpt == st.wpt) {
+            B1Conv p0 = T.back().c[0], n0 = st.c[0];
+            p0.x_off = p0.y_off = p0.add_off = p0.w_off = p0.scale_off = p0.shift_off = 0;
+            n0.x_off = n0.y_off = n0.add_off = n0.w_off = n0.scale_off = n0.shift_off = 0;
+            p0.relu = p0.relu_post = p0.has_add = n0.relu = n0.relu_post = n0.has_add = 0;
+            st.same_shape = memcmp(&p0, &n0, sizeof(B1Conv)) == 0;
+        }
+        if (getenv("CILRS_B1_FINE"))
+            fprintf(stderr, "b1 stage %2d: wpt %2d units %4d (ks %d nt %d per %d | ks %d nt %d per %d) same %d\n",
+                    (int)T.size(), st.wpt, st.total_units, st.c[0].ksplit, st.c[0].nt, st.c[0].per,
+                    c1 ? st.c[1].ksplit : 0, c1 ? st.c[1].nt : 0, c1 ? st.c[1].per : 0, st.same_shape);
         T.push_back(st);
     };
     {   // uint8 frame -> normalised NHWC4
@@ -1487,6 +1502,7 @@ static int b1_build(cilrs_net* net, int nblk) {
         st.h.se_w0 = fb(A.se0.w); st.h.se_b0 = fb(A.se0.b);
         st.h.se_w1 = fb(A.se3.w); st.h.se_b1 = fb(A.se3.b);
         st.h.y_off[0] = fb(net->s1);
+        st.cmd_off = fb(net->b1_cmd);
         T.push_back(st);
     }
     push_conv_stage(B1_STEM, conv_desc(0, net->x4, false, 0, 1, 0), nullptr);
@@ -1521,6 +1537,7 @@ static int b1_build(cilrs_net* net, int nblk) {
         B1Stage st;
         memset(&st, 0, sizeof(st));
         st.type = B1_HEAD;
+        st.cmd_off = fb(net->b1_cmd);
         B1Head& h = st.h;
         for (int k = 0; k < 4; ++k) {
             h.w_off[k] = fb(A.br[k][layer].w);
@@ -1552,11 +1569,12 @@ static int b1_build(cilrs_net* net, int nblk) {
     return 0;
 }
 
-int cilrs_net_forward_u8_b1(cilrs_net* net, const cilrs_buffers* bufs, const uint8_t* frame,
-                            const float* speed, const int64_t* command, float* controls,
-                            float* pred_speed, void* stream) {
+static int b1_launch(cilrs_net* net, const cilrs_buffers* bufs, const uint8_t* frame,
+                     int first_stage, const float* speed, const int64_t* command, float* controls,
+                     float* pred_speed, void* stream) {
     if (check_bufs(net, bufs, false)) return 1;
-    CILRS_CHECK(frame && speed && command && controls && pred_speed, "forward_u8_b1: NULL tensor");
+    CILRS_CHECK((frame || first_stage == 1) && speed && command && controls && pred_speed,
+                "forward_u8_b1: NULL tensor");
     CILRS_CHECK(net->B == 1 && net->A->variant == 0 && net->b1_table != 0,
                 "forward_u8_b1: the persistent kernel serves the reference network at batch 1");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -1581,6 +1599,7 @@ int cilrs_net_forward_u8_b1(cilrs_net* net, const cilrs_buffers* bufs, const uin
     memset(&a, 0, sizeof(a));
     a.table = reinterpret_cast<const B1Stage*>(ws + net->b1_table);
     a.nstages = (int)net->b1_host.size();
+    a.first_stage = first_stage;
     a.ws = ws; a.ws_bytes = net->ws_bytes;
     a.params = bufs->params; a.param_bytes = net->A->arena_floats * sizeof(float);
     a.frame = frame; a.speed = speed; a.cmd = reinterpret_cast<const long long*>(command);
@@ -1595,6 +1614,38 @@ int cilrs_net_forward_u8_b1(cilrs_net* net, const cilrs_buffers* bufs, const uin
     RUN(net, "infer_b1", 2.0 * 2.798e9 / 2.0, 0.0, s, launch_infer_b1(a, net->b1_blocks, s));
     net->trained_fwd = false;
     net->last_dropout = 0.f;
+    return 0;
+}
+
+int cilrs_net_forward_u8_b1(cilrs_net* net, const cilrs_buffers* bufs, const uint8_t* frame,
+                            const float* speed, const int64_t* command, float* controls,
+                            float* pred_speed, void* stream) {
+    return b1_launch(net, bufs, frame, 0, speed, command, controls, pred_speed, stream);
+}
+
+int cilrs_net_forward_camera_b1(cilrs_net* net, const cilrs_buffers* bufs, const uint8_t* frame,
+                                int src_h, int src_w, int pixel_stride, long row_stride,
+                                const float* speed, const int64_t* command, float* controls,
+                                float* pred_speed, int sync, void* stream) {
+    if (check_bufs(net, bufs, false)) return 1;
+    CILRS_CHECK(frame != nullptr, "forward_camera_b1: NULL frame");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    float* ws = reinterpret_cast<float*>(bufs->workspace);
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    RUN(net, "transform", 0.0, 0.0, s,
+        launch_camera_to_nhwc4(frame, ws + net->x4, 1, src_h, src_w, pixel_stride, row_stride,
+                               (long)src_h * row_stride, net->H, net->W, mean, stdv, s));
+    if (b1_launch(net, bufs, nullptr, 1, speed, command, controls, pred_speed, stream)) return 1;
+    if (sync) CILRS_HIP(hipStreamSynchronize(s));
+    return 0;
+}
+
+int cilrs_net_forward_u8_b1_sync(cilrs_net* net, const cilrs_buffers* bufs, const uint8_t* frame,
+                                 const float* speed, const int64_t* command, float* controls,
+                                 float* pred_speed, void* stream) {
+    if (cilrs_net_forward_u8_b1(net, bufs, frame, speed, command, controls, pred_speed, stream))
+        return 1;
+    CILRS_HIP(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
     return 0;
 }
 

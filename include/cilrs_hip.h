@@ -193,6 +193,20 @@ int cilrs_net_forward_u8_graph(cilrs_net* net, const cilrs_buffers* bufs, const 
 int cilrs_net_forward_u8_b1(cilrs_net* net, const cilrs_buffers* bufs, const uint8_t* frame,
                             const float* speed, const int64_t* command, float* controls,
                             float* pred_speed, void* stream);
+/* The agent's whole tick on a raw camera frame (preprocess_image + model call,
+ * model/autonomous_drive.py:897-920): the fused resize / normalise transform of
+ * cilrs_net_forward_camera, then the persistent launch from its second stage.  `frame` may be
+ * pinned host memory; sync != 0 ends with hipStreamSynchronize(stream). */
+int cilrs_net_forward_camera_b1(cilrs_net* net, const cilrs_buffers* bufs, const uint8_t* frame,
+                                int src_h, int src_w, int pixel_stride, long row_stride,
+                                const float* speed, const int64_t* command, float* controls,
+                                float* pred_speed, int sync, void* stream);
+/* ... followed by hipStreamSynchronize(stream): one library call per control-loop tick when the
+ * frame / speed / command and the outputs live in pinned host memory (the kernel reads and writes
+ * them in place; no copy commands). */
+int cilrs_net_forward_u8_b1_sync(cilrs_net* net, const cilrs_buffers* bufs, const uint8_t* frame,
+                                 const float* speed, const int64_t* command, float* controls,
+                                 float* pred_speed, void* stream);
 /* number of stages (= grid barriers + 1) of that launch; -1 before the first call, 0 if the plan
  * has no persistent path */
 int cilrs_net_b1_stages(cilrs_net* net);
