@@ -58,6 +58,8 @@ SIGNATURES = {
     "cilrs_net_workspace_bytes": (sz, [vp]),
     "cilrs_net_status_offset": (sz, [vp]),
     "cilrs_net_set_weights_key": (i32, [vp, u64]),
+    "cilrs_net_activation_info": (i32, [vp, i32, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz),
+                                        C.POINTER(i32)]),
     "cilrs_dropout": (i32, [vp, i32, i32, i32, f32, u64, i32, vp]),
     "cilrs_net_forward": (i32, [vp, C.POINTER(Buffers), vp, C.c_long, C.c_long, C.c_long,
                                 C.c_long, vp, vp, i32, f32, u64, vp, vp, vp]),

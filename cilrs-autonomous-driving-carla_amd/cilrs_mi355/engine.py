@@ -83,9 +83,12 @@ class Plan:
         self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=device)
         assert self.workspace.data_ptr() % 256 == 0
         # int32[4] status words inside the workspace (word 0: a command outside 0..3 was seen by
-        # the last forward -- the reference's torch.gather raises there, autonomous_drive.py:397)
+        # a forward SINCE THE LAST check_status() -- the reference's torch.gather raises there,
+        # autonomous_drive.py:397; kernels only ever set the words, so one read at the end of an
+        # epoch covers every batch; word 1: a grid barrier of the persistent launch gave up)
         off = lib.cilrs_net_status_offset(handle)
         self.status = self.workspace[off:off + 16].view(torch.int32)
+        self.status.zero_()
         self.generation = 0
 
     def __del__(self):
@@ -100,6 +103,8 @@ class Plan:
         """Synchronising read of the status words of the last forward on this plan; raises what
         the reference's ``all_out.gather(0, idx)`` raises for an out-of-range command."""
         st = self.status.tolist()
+        if st[0] != 0 or st[1] != 0:
+            self.status.zero_()           # the words are sticky: "since the last check"
         if st[1] != 0:
             raise RuntimeError("CILRS persistent forward: a grid barrier gave up (another "
                                "persistent launch was holding the device); outputs are NaN")
@@ -191,6 +196,9 @@ class Engine:
         # Trainer(..., precision=) or directly before the first train-mode forward
         self.train_precision = "fp32"
         self._scratch_grads = None        # second gradient arena (autograd accumulation only)
+        # False: loss.backward() hands autograd CLONES of the gradient arena (torch semantics: they
+        # stay valid whatever runs next).  True: views of the arena, valid until the next backward.
+        self.zero_copy_grads = False
         self.weights_epoch = 1            # bumped by every kernel-side write to params / BN buffers
 
     # ------------------------------------------------------------------------------------------
@@ -389,17 +397,22 @@ class _CILRSFunction(torch.autograd.Function):
             dcontrols = torch.zeros(b, 3, device=eng.device)
         if dpred_speed is None:
             dpred_speed = torch.zeros(b, device=eng.device)
-        # Autograd gets VIEWS of the arena the kernels wrote (no 89.7 MB copy).  Only when some
-        # p.grad already lives in that arena (autograd kept a view from an earlier backward and
-        # the caller did not reset it to None) would writing there clobber the value autograd is
-        # about to accumulate into: that backward goes to a second arena instead.
+        # torch semantics: what backward hands to autograd must stay valid for as long as anyone
+        # holds it (autograd's own input buffers while several CILRS nodes of one graph are
+        # summed, results of torch.autograd.grad, saved p.grad lists).  The kernels write into the
+        # engine's gradient arena, which the NEXT backward overwrites -- so by default autograd
+        # gets a clone (89.7 MB device copy, ~30 us).  `engine.zero_copy_grads = True` opts into
+        # views of the arena for loops that consume the gradients before the next backward
+        # (optimizer.step() + zero_grad(set_to_none=True)); when some p.grad still lives in the
+        # arena that backward is written to a second arena instead, so accumulation stays correct.
         dst = eng.grads
-        if eng.grads_aliased():
+        if eng.zero_copy_grads and eng.grads_aliased():
             if eng._scratch_grads is None:
                 eng._scratch_grads = torch.zeros_like(eng.grads)
             dst = eng._scratch_grads
         eng.run_backward(pl, dcontrols.contiguous().float(), dpred_speed.contiguous().float(),
                          into=None if dst is eng.grads else dst)
-        grads = [_arena_view(dst, off, numel, shape)
+        src = dst if eng.zero_copy_grads else dst.clone()
+        grads = [_arena_view(src, off, numel, shape)
                  for (_, off, numel, shape) in eng.params_layout]
         return (None, None, None, None, None, None, *grads)

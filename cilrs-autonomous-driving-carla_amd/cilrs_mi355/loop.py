@@ -10,6 +10,8 @@ import csv
 import os
 import time
 
+import torch
+
 from . import checkpoint
 from .train import LOSS_KEYS
 
@@ -28,6 +30,11 @@ def train_one_epoch(trainer, batches):
         buf = trainer.train_step(imgs, speeds, cmds, tgts)
         acc = buf[:6].double().clone() if acc is None else acc + buf[:6].double()
         n += 1
+    if acc is not None and trainer.reducer is not None:
+        # data parallel: the epoch mean over ALL ranks' batches (every rank logs / checks the same)
+        packed = trainer.all_reduce_sum(torch.cat([acc, torch.tensor([float(n)], dtype=torch.float64,
+                                                                    device=acc.device)]))
+        acc, n = packed[:6], float(packed[6])
     vals = (acc / max(n, 1)).tolist() if acc is not None else [float("nan")] * 6
     if acc is not None:
         trainer.eng.check_status()                  # out-of-range command in the last batch
@@ -41,7 +48,17 @@ def fit(trainer, train_batches, val_batches, epochs=20, patience=6, out_dir=".",
         log=print):
     """``train_batches`` / ``val_batches``: callables returning an iterable of
     (imgs, speeds, cmds, tgts) device batches for one epoch."""
-    os.makedirs(out_dir, exist_ok=True)
+    # data parallel: metrics are all-reduced (Trainer.validate / train_one_epoch), so every rank
+    # takes the same decisions; rank 0 alone writes the checkpoints and the history
+    writer = trainer.rank == 0
+
+    def barrier():
+        if trainer.reducer is not None:
+            import torch.distributed as dist
+            dist.barrier(group=trainer.reducer.pg)
+    if writer:
+        os.makedirs(out_dir, exist_ok=True)
+    barrier()
     best_path = os.path.join(out_dir, "checkpoint_best.pth")
     latest_path = os.path.join(out_dir, "checkpoint_latest.pth")
     start_epoch, best_val, best_epoch, bad = 1, float("inf"), 0, 0
@@ -71,19 +88,25 @@ def fit(trainer, train_batches, val_batches, epochs=20, patience=6, out_dir=".",
             f"({dt:.1f}s)")
         if va["total"] < best_val:                                 # nb:627-637
             best_val, best_epoch, bad = va["total"], epoch, 0
-            checkpoint.save_best(best_path, trainer.model, trainer, epoch, va["total"],
-                                 va["steer"], cmd)
+            if writer:
+                checkpoint.save_best(best_path, trainer.model, trainer, epoch, va["total"],
+                                     va["steer"], cmd)
         else:
             bad += 1
-        checkpoint.save_latest(latest_path, trainer.model, trainer, epoch,    # nb:642-646
-                               loop_state={"best_val": float(best_val), "best_epoch": best_epoch,
-                                           "bad": bad, "history": history})
+        if writer:
+            checkpoint.save_latest(latest_path, trainer.model, trainer, epoch,    # nb:642-646
+                                   loop_state={"best_val": float(best_val),
+                                               "best_epoch": best_epoch, "bad": bad,
+                                               "history": history})
+        barrier()
         if bad >= patience:                                        # nb:650-652
             log(f"early stopping at epoch {epoch}")
             break
-    with open(os.path.join(out_dir, "training_history.csv"), "w", newline="") as f:
-        w = csv.DictWriter(f, fieldnames=HISTORY_COLUMNS)
-        w.writeheader()
-        for row in history:
-            w.writerow({k: row.get(k, "") for k in HISTORY_COLUMNS})
+    if writer:
+        with open(os.path.join(out_dir, "training_history.csv"), "w", newline="") as f:
+            w = csv.DictWriter(f, fieldnames=HISTORY_COLUMNS)
+            w.writeheader()
+            for row in history:
+                w.writerow({k: row.get(k, "") for k in HISTORY_COLUMNS})
+    barrier()
     return dict(best_val_loss=best_val, best_epoch=best_epoch, history=history)

@@ -125,6 +125,8 @@ class CILRS(nn.Module):
         # from them for inference (engine.weights_key)
         self.register_load_state_dict_post_hook(lambda module, _keys: module.weights_changed())
 
+    _live = None          # weak set of modules with an engine (global optimizer hook below)
+
     def weights_changed(self):
         """Tell the engine that parameters or BatchNorm buffers were modified in place (it then
         re-derives its cached inference state: folded BatchNorm scale/shift, 16-bit weights).
@@ -150,6 +152,7 @@ class CILRS(nn.Module):
         if eng is None or not eng.is_attached():
             eng = Engine(self, self.VARIANT)
             self._engine = eng
+            _track(self)
         return eng
 
     # -- the reference's forward signature -----------------------------------------------------
@@ -164,6 +167,26 @@ class CILRS(nn.Module):
             self._dropout_calls += 1
             seed = dropout_seed(torch.initial_seed(), self._dropout_calls, rank)
         return eng.forward(image, speed, command, self.training, p, seed)
+
+
+def _track(module):
+    """In-place parameter writes made while the module stays in eval mode (frozen-BatchNorm
+    fine-tuning with torch.optim, ...) must invalidate the engine's cached inference state.  One
+    global optimizer post-step hook bumps the weights epoch of every live engine whose parameters
+    the stepping optimizer owns."""
+    import weakref
+    if CILRS._live is None:
+        CILRS._live = weakref.WeakSet()
+
+        def _after_step(optimizer, *_a, **_k):
+            owned = {id(p) for g in optimizer.param_groups for p in g["params"]}
+            for m in list(CILRS._live):
+                eng = m._engine
+                if eng is not None and id(eng._first_param) in owned:
+                    eng.weights_epoch += 1
+        from torch.optim.optimizer import register_optimizer_step_post_hook
+        register_optimizer_step_post_hook(_after_step)
+    CILRS._live.add(module)
 
 
 class CILRSResNet50(CILRS):

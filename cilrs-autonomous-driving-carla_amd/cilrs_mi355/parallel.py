@@ -65,6 +65,7 @@ def broadcast_parameters(eng, process_group=None, src=0):
     pg = process_group if process_group is not None else dist.group.WORLD
     for t in (eng.params, eng.bn, eng.nbt):
         dist.broadcast(t, src=src, group=pg)
+    eng.weights_epoch += 1            # cached eval-mode state (folded BatchNorm, graphs) is stale
 
 
 def init_from_env(backend=None):

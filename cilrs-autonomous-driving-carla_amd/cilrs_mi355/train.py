@@ -40,6 +40,12 @@ def dropout_seed(torch_seed: int, call: int, rank: int = 0) -> int:
     return ((torch_seed * 1000003 + call) ^ (rank * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
 
 
+def steplr(cfg: TrainConfig, epoch: int) -> float:
+    """lr in effect AFTER `epoch` scheduler steps of torch.optim.lr_scheduler.StepLR(step_size,
+    gamma) (nb:535-536: StepLR(8, 0.5), stepped once per epoch, nb:604)."""
+    return cfg.lr * (cfg.lr_gamma ** (epoch // cfg.lr_step_size))
+
+
 CONFIG_A = TrainConfig()
 CONFIG_B = TrainConfig(name="B", lr=1e-4, loss="l1", loss_weights=(5.0, 1.0, 1.0, 0.5),
                        grad_clip=1.0, dropout=0.5)
@@ -175,7 +181,7 @@ class Trainer:
     # -- StepLR (nb:535-536, 604) ----------------------------------------------------------------
     def scheduler_step(self):
         self.epoch += 1
-        self.lr = self.cfg.lr * (self.cfg.lr_gamma ** (self.epoch // self.cfg.lr_step_size))
+        self.lr = steplr(self.cfg, self.epoch)
 
     # -- validate() (nb:563-585) -------------------------------------------------------------------
     @torch.no_grad()
@@ -195,8 +201,23 @@ class Trainer:
             serr = (pc[:, 0] - tgts[:, 0]).abs().double()
             cmd_sum.index_add_(0, cmds, serr)
             cmd_cnt.index_add_(0, cmds, torch.ones_like(serr))
-        out = {k: float(sums[i]) / max(n, 1) for i, k in enumerate(LOSS_KEYS)}
-        cs, cc = cmd_sum.cpu(), cmd_cnt.cpu()
+        # data parallel: every rank validates its own shard; the SUMS are all-reduced so that all
+        # ranks see the same metrics and take the same early-stopping / checkpoint decisions (a
+        # rank that stopped alone would leave the others hanging in the next gradient all-reduce)
+        packed = torch.cat([sums.to(self.eng.device), torch.tensor([float(n)], dtype=torch.float64,
+                                                                  device=self.eng.device),
+                            cmd_sum, cmd_cnt])
+        packed = self.all_reduce_sum(packed)
+        sums, n, cs, cc = packed[:6].cpu(), float(packed[6]), packed[7:11].cpu(), packed[11:15].cpu()
+        out = {k: float(sums[i]) / max(n, 1.0) for i, k in enumerate(LOSS_KEYS)}
         cmd_avg = {CMD_NAMES[i]: (float(cs[i] / cc[i]) if cc[i] > 0 else float("nan"))
                    for i in range(4)}
         return out, cmd_avg
+
+    def all_reduce_sum(self, t):
+        """Sum of a (device) tensor over the data-parallel ranks; the tensor itself without them."""
+        if self.reducer is None:
+            return t
+        import torch.distributed as dist
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.reducer.pg)
+        return t

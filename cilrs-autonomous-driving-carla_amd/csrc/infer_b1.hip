@@ -614,7 +614,7 @@ __device__ __forceinline__ void head_stage(const B1Stage* st, const B1Launch& a,
     float* x1 = hx + 640;
     if (first) {
         // a command outside 0..3: torch.gather would raise (:397-398); the host reads this word
-        if (blockIdx.x == 0 && tid == 0) a.status[0] = cmd < 0 ? 1 : 0;
+        if (blockIdx.x == 0 && tid == 0 && cmd < 0) a.status[0] = 1;      // sticky: the host clears it
         const int HW = RFL(h->featHW), C = RFL(h->featC);
         const unsigned fo = (unsigned)RFL(h->feat_off);
         if (tid < (C >> 2)) {              // AdaptiveAvgPool2d(1,1) + Flatten (:369); pixel order
@@ -718,11 +718,7 @@ __global__ __launch_bounds__(kThreads) void infer_b1_kernel(const B1Launch a) {
     base = RFL(base);
     for (int i = tid; i < nstages * kDescInts; i += kThreads)      // the stage table, once
         desc[i] = reinterpret_cast<const int*>(a.table)[i];
-    if (tid == 0) {
-        fail = 0;
-        if (blockIdx.x == 0)     // a give-up (>= 1 s of polling) cannot race this store
-            __hip_atomic_store(a.status + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (tid == 0) fail = 0;
     // the command may live in pinned HOST memory (zero-copy control loop): read it once, here, and
     // park it next to the activations -- the three head stages then do not cross PCIe
     if (blockIdx.x == 0 && tid == 0) {

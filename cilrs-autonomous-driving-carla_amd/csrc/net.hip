@@ -892,6 +892,26 @@ void cilrs_net_destroy(cilrs_net* net) {
 size_t cilrs_net_workspace_bytes(const cilrs_net* net) { return net ? net->ws_bytes : 0; }
 size_t cilrs_net_status_offset(const cilrs_net* net) { return net ? net->status_b : 0; }
 
+int cilrs_net_activation_info(const cilrs_net* net, int conv, size_t* y_offset, size_t* z_offset,
+                              size_t* numel, int* channels) {
+    CILRS_CHECK(net != nullptr, "activation_info: net is NULL");
+    // conv -1: the max-pool output (input of the first residual block)
+    if (conv == -1) {
+        if (y_offset) *y_offset = net->pool;
+        if (z_offset) *z_offset = net->pool;
+        if (numel) *numel = (size_t)net->B * net->H1 * net->W1 * 64;
+        if (channels) *channels = 64;
+        return 0;
+    }
+    CILRS_CHECK(conv >= 0 && conv < (int)net->cg.size(), "activation_info: conv %d out of range", conv);
+    const ConvG& g = net->cg[conv];
+    if (y_offset) *y_offset = g.y;
+    if (z_offset) *z_offset = g.z;
+    if (numel) *numel = (size_t)g.M * net->A->convs[conv].cout;
+    if (channels) *channels = net->A->convs[conv].cout;
+    return 0;
+}
+
 int cilrs_net_set_weights_key(cilrs_net* net, uint64_t key) {
     CILRS_CHECK(net != nullptr, "set_weights_key: net is NULL");
     net->weights_key = key;
@@ -1286,7 +1306,6 @@ int cilrs_net_forward(cilrs_net* net, const cilrs_buffers* bufs, const float* im
     CILRS_CHECK(image && speed && command && controls && pred_speed, "forward: NULL tensor");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     float* ws = reinterpret_cast<float*>(bufs->workspace);
-    CILRS_HIP(hipMemsetAsync(reinterpret_cast<char*>(bufs->workspace) + net->status_b, 0, 16, s));
     RUN(net, "transform", 0.0, 0.0, s,
         launch_nchw3_to_nhwc4(image, ws + net->x4, net->B, net->H, net->W, sn, sc, sh, sw, s));
     return forward_from_x4(net, bufs, speed, command, train, dropout_p, seed, controls,
@@ -1300,7 +1319,6 @@ int cilrs_net_forward_u8(cilrs_net* net, const cilrs_buffers* bufs, const uint8_
     CILRS_CHECK(frames && speed && command && controls && pred_speed, "forward_u8: NULL tensor");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     float* ws = reinterpret_cast<float*>(bufs->workspace);
-    CILRS_HIP(hipMemsetAsync(reinterpret_cast<char*>(bufs->workspace) + net->status_b, 0, 16, s));
     const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
     RUN(net, "transform", 0.0, 0.0, s,
         launch_u8hwc_to_nhwc4(frames, ws + net->x4, (size_t)net->B * net->H * net->W, mean, stdv,
@@ -1317,7 +1335,6 @@ int cilrs_net_forward_camera(cilrs_net* net, const cilrs_buffers* bufs, const ui
                 "forward_camera: NULL tensor");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     float* ws = reinterpret_cast<float*>(bufs->workspace);
-    CILRS_HIP(hipMemsetAsync(reinterpret_cast<char*>(bufs->workspace) + net->status_b, 0, 16, s));
     const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
     RUN(net, "transform", 0.0, 0.0, s,
         launch_camera_to_nhwc4(frames, ws + net->x4, net->B, src_h, src_w, pixel_stride,
@@ -1333,7 +1350,6 @@ int cilrs_net_forward_u8_f16(cilrs_net* net, const cilrs_buffers* bufs, const ui
                 "forward_u8_f16: NULL tensor");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     float* ws = reinterpret_cast<float*>(bufs->workspace);
-    CILRS_HIP(hipMemsetAsync(reinterpret_cast<char*>(bufs->workspace) + net->status_b, 0, 16, s));
     const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
     RUN(net, "transform", 0.0, 0.0, s,
         launch_u8hwc_to_nhwc4(frames, ws + net->x4, (size_t)net->B * net->H * net->W, mean, stdv,
@@ -1349,7 +1365,6 @@ int cilrs_net_forward_u8_bf16(cilrs_net* net, const cilrs_buffers* bufs, const u
                 "forward_u8_bf16: NULL tensor");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     float* ws = reinterpret_cast<float*>(bufs->workspace);
-    CILRS_HIP(hipMemsetAsync(reinterpret_cast<char*>(bufs->workspace) + net->status_b, 0, 16, s));
     const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
     RUN(net, "transform", 0.0, 0.0, s,
         launch_u8hwc_to_nhwc4(frames, ws + net->x4, (size_t)net->B * net->H * net->W, mean, stdv,
@@ -1590,8 +1605,7 @@ static int b1_launch(cilrs_net* net, const cilrs_buffers* bufs, const uint8_t* f
     if (eval_prep(net, bufs, s)) return 1;
     if (net->b1_ready_for != bufs->workspace) {
         CILRS_HIP(hipMemsetAsync(ws + net->b1_sync, 0, kB1SyncInts * sizeof(int), s));
-        CILRS_HIP(hipMemsetAsync(reinterpret_cast<char*>(bufs->workspace) + net->status_b, 0, 16, s));
-        CILRS_HIP(hipMemcpyAsync(ws + net->b1_table, net->b1_host.data(),
+            CILRS_HIP(hipMemcpyAsync(ws + net->b1_table, net->b1_host.data(),
                                  net->b1_host.size() * sizeof(B1Stage), hipMemcpyHostToDevice, s));
         net->b1_ready_for = bufs->workspace;
     }
@@ -1715,7 +1729,10 @@ static int forward_u8_graph(cilrs_net* net, const cilrs_buffers* bufs, const uin
         // first call eager: function attributes, side streams, events; and whenever the weights
         // key moved, so that the weight-derived state is rebuilt OUTSIDE the capture and the graph
         // holds only the per-frame kernels
-        if (!net->warmed || net->prep_key != net->weights_key || net->weights_key == 0) {
+        // ... and whenever the 16-bit fold state is stale (another mode ran in between): the fold
+        // kernels must not be captured into the per-frame graph
+        const bool fold_stale = half && (net->fold_key != net->weights_key || net->fold_half != half);
+        if (!net->warmed || net->prep_key != net->weights_key || net->weights_key == 0 || fold_stale) {
             if (ensure_streams(net)) return 1;
             if (eager(net, bufs, frames, speed, command, controls, pred_speed, stream)) return 1;
             CILRS_HIP(hipStreamSynchronize(s));

@@ -122,6 +122,15 @@ size_t cilrs_net_status_offset(const cilrs_net* net);
  * bumps on every train-mode forward and optimiser step. */
 int cilrs_net_set_weights_key(cilrs_net* net, uint64_t key);
 
+/* Where a train-mode forward left the tensors backward re-reads, as float offsets into the
+ * workspace (NHWC, dense): convolution `conv` (parameter order: 0 stem, then every block's conv1,
+ * conv2[, conv3][, downsample]) -- y = its raw output (input of its BatchNorm), z = after BatchNorm
+ * (+ residual) (+ ReLU); conv -1: the max-pool output.  The stem's z is not materialised in train
+ * mode (BatchNorm + ReLU are fused into the max-pool).  Test / diagnostics aid: the parity tests
+ * count the ReLU decisions on which the engine and the oracle differ. */
+int cilrs_net_activation_info(const cilrs_net* net, int conv, size_t* y_offset, size_t* z_offset,
+                              size_t* numel, int* channels);
+
 /* nn.Dropout(p) in training mode exactly as the fused heads apply it (inverted dropout, keep
  * where hash(seed, site, row * cols + col) >= p, kept values divided by 1 - p), in place over
  * a [rows][cols] matrix with row pitch ld.  `site` names the Dropout module:

@@ -547,3 +547,27 @@ def test_torchvision_trunk_keys_map_onto_the_reference_wrapping():
                        tv.state_dict()["layer2.0.downsample.0.weight"])
     with pytest.raises(KeyError):
         checkpoint.trunk_state_from_torchvision({"stem.weight": torch.zeros(1)})
+
+
+def test_steplr_matches_torch_steplr_for_20_epochs():
+    """Trainer.scheduler_step's formula against torch.optim.lr_scheduler.StepLR(8, 0.5), the
+    reference's scheduler (notebook/notebook.ipynb:535-536), stepped once per epoch (nb:604) for
+    20 epochs: the decays at epochs 8 and 16 included."""
+    import torch
+    from cilrs_mi355.train import CONFIG_A, CONFIG_B, TrainConfig, steplr
+    for cfg in (CONFIG_A, CONFIG_B, TrainConfig(lr=3e-4, lr_step_size=3, lr_gamma=0.7)):
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.Adam([p], lr=cfg.lr)
+        sched = torch.optim.lr_scheduler.StepLR(opt, step_size=cfg.lr_step_size, gamma=cfg.lr_gamma)
+        assert steplr(cfg, 0) == cfg.lr
+        for epoch in range(1, 21):
+            opt.step()
+            sched.step()
+            want = opt.param_groups[0]["lr"]
+            got = steplr(cfg, epoch)
+            assert abs(got - want) <= 1e-15 + 1e-12 * want, (cfg.name, epoch, got, want)
+            if cfg.lr_gamma == 0.5:
+                assert got == want                      # powers of two: exact
+        if cfg.lr_step_size == 8:
+            assert steplr(cfg, 7) == cfg.lr and steplr(cfg, 8) == cfg.lr * 0.5
+            assert steplr(cfg, 15) == cfg.lr * 0.5 and steplr(cfg, 16) == cfg.lr * 0.25

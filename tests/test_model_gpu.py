@@ -122,29 +122,28 @@ def _fp64_grads(ocfg, imgs, spds, cmds, tgts, build=None):
     return {n: p.grad for n, p in m64.named_parameters()}
 
 
-# Fraction of a tensor's elements allowed to differ by more than 2e-5 after k Adam steps, and the
-# count allowed in tensors too small for a fraction to mean anything.  Measured on MI355X with
-# tests/calibrate_param_outliers.py (profiles/r02_param_outliers.log): see OUTLIER_FRAC below.
-#   one step from identical state (Adam's step-1 update is lr*sign(g), so only sign flips of
-#   near-zero gradients show): 2.5e-6 (B=4) ... 2.8e-3 (B=5, 64x64 frames) of all elements,
-#   1.1e-3 at B=128; worst tensor 6.3e-3; at most 4 elements in any tensor below 4096 elements
-#   -> gate 2e-2 per tensor (3x the worst seen), floor 8;
-#   free-running trajectories (every later update depends on the RATIO of noisy gradients, and
-#   the parameters already differ): step 2 up to 7.6e-2 / 29, step 3 up to 0.24 / 77 per tensor
-#   -> gates 0.25 / 0.6 -- by then only the hard bound is a real check, which is why the
-#   optimiser's arithmetic is pinned separately (re-synchronised step below, Adam op test)
-OUTLIER_FRAC = {1: 2e-2, 2: 0.25, 3: 0.6}
-OUTLIER_FLOOR = {1: 8, 2: 64, 3: 160}
+# Parameters after k Adam steps.  Adam's first update is lr*sign(g): an element whose gradient is
+# within fp32 noise of zero may differ by 2*lr whatever the implementation.  Measured on MI355X
+# with tests/calibrate_param_outliers.py (profiles/r02_param_outliers.log), ONE step from identical
+# state: 2.5e-6 (B=4) ... 2.8e-3 (B=5, 64x64 frames) of all elements beyond 2e-5, 1.1e-3 at B=128,
+# worst tensor 6.3e-3, at most 4 elements in any tensor below 4096 elements
+#   -> one-step gate: 1.3e-2 of a tensor's elements (2x the worst observed), floor 8 elements.
+# Free-running trajectories (k >= 2) drift: every later update depends on the RATIO of noisy
+# gradients and the parameters already differ (4.6 % of elements by step 2 at B=128) -- a fraction
+# gate there would only restate the hard bound, so there is none: for k >= 2 the hard bound
+# 2.2*lr*k is the check, and the optimiser's arithmetic WITH history is pinned by the
+# re-synchronised step of test_train_steps_golden_and_oracle (state loaded from the oracle, one
+# more step at the one-step gate) and element-wise by test_ops_gpu.py::test_adam_step_matches_torch_adam.
+OUTLIER_FRAC_1 = 1.3e-2
+OUTLIER_FLOOR_1 = 8
 
 
 def _close_params(mine, want, lr, steps):
-    """Adam's update is ~lr*sign(g) per step, so an element whose gradient is within rounding of
-    zero may legitimately differ by 2*lr per step; everything else must agree to ~1e-6."""
     err = (mine - want).abs()
     assert float(err.max()) <= 2.2 * lr * steps + 1e-6
-    nbad = int((err > 2e-5).sum())
-    k = min(steps, 3)
-    assert nbad <= max(OUTLIER_FLOOR[k], int(OUTLIER_FRAC[k] * err.numel())), (nbad, err.numel())
+    if steps == 1:
+        nbad = int((err > 2e-5).sum())
+        assert nbad <= max(OUTLIER_FLOOR_1, int(OUTLIER_FRAC_1 * err.numel())), (nbad, err.numel())
 
 
 @pytest.mark.parametrize("cfg_name", ["A", "B"])
@@ -615,10 +614,15 @@ def test_full_batch_properties_b128():
 
 
 # ---- round 2: the benchmark batch, dropout with known masks, status words -----------------------
-def _grad_budget_check(tag, named_oracle_params, gv, g64, coef, cos_floor=1e-5):
+def _grad_budget_check(tag, named_oracle_params, gv, g64, coef, cos_floor=1e-5, realisations=None):
     """Per-tensor relative-L2 error of the HIP gradients against float64, budgeted against the
     fp32 CPU oracle's own error; 1 - cos of the full gradient <= max(4x the CPU path's,
-    cos_floor).  Returns 1 - cos."""
+    cos_floor).  Returns 1 - cos.
+    realisations: gradients of the same step from OTHER fp32 CPU realisations (thread count,
+    memory format).  With them the per-tensor floor is what those realisations show -- the worst
+    of their errors against float64 and of their distances from each other, times 2 -- instead
+    of the constant 5e-3 (round 2's gate flipped on a tensor at 5.57e-3 after a legal change of
+    summation order; measured here the CPU realisations themselves sit up to ~1e-2 apart)."""
     dot = n1 = n2 = 0.0
     cdot = cn1 = 0.0
     worst_gpu = worst_cpu = 0.0
@@ -629,7 +633,15 @@ def _grad_budget_check(tag, named_oracle_params, gv, g64, coef, cos_floor=1e-5):
         nrm = max(float(ref64.norm()), 1e-30)
         e_gpu = float((mine - ref64).norm()) / nrm
         e_cpu = float((p.grad.double() - ref64).norm()) / nrm
-        assert e_gpu <= max(4.0 * e_cpu, 5e-3), (tag, n, e_gpu, e_cpu)
+        if realisations is None:
+            assert e_gpu <= max(4.0 * e_cpu, 5e-3), (tag, n, e_gpu, e_cpu)
+        else:
+            alts = [p.grad.double() * 1.0] + [r[n].double() * coef for r in realisations]
+            e_alt = [float((a - ref64).norm()) / nrm for a in alts]
+            spread = max(float((alts[i] - alts[j]).norm()) / nrm
+                         for i in range(len(alts)) for j in range(i))
+            floor = max(max(e_alt), spread)
+            assert e_gpu <= max(4.0 * e_cpu, 2.0 * floor), (tag, n, e_gpu, e_alt, spread)
         gmax = max(float(ref64.abs().max()), 1e-12)
         m_gpu = float((mine - ref64).abs().max())
         m_cpu = float((p.grad.double() - ref64).abs().max())
@@ -701,8 +713,15 @@ def test_train_step_b128_vs_oracle(cfg_name):
         n64 = float(torch.sqrt(sum((g.double() ** 2).sum() for g in g64.values())))
         assert abs(gn - n64) <= 5e-4 * n64
         coef = min(1.0, cfg.grad_clip / (n64 + 1e-6))
+    # a second fp32 CPU realisation of the same step (channels_last input: other convolution
+    # kernels, other summation orders): the noise floor of the gate is measured, not assumed
+    alt = O.build_oracle(0).train()
+    pc2, ps2 = alt(imgs.contiguous(memory_format=torch.channels_last), spds, cmds)
+    loss2, _ = O.compute_loss(ocfg, pc2, tgts, ps2, spds)
+    loss2.backward()
+    alt_g = {n: p.grad for n, p in alt.named_parameters()}       # unclipped; the check scales it
     omc = _grad_budget_check(f"B=128 cfg {cfg_name}", list(orc.named_parameters()),
-                             _grad_views(eng), g64, coef)
+                             _grad_views(eng), g64, coef, realisations=[alt_g])
     assert omc <= 1e-5
     # train-mode BatchNorm at B = 128: running statistics of all 36 layers, element-wise
     sd, osd = m.state_dict(), orc.state_dict()
@@ -860,12 +879,13 @@ def test_non_finite_loss_is_reported():
     assert tr.losses(check=False)["total"] != tr.losses(check=False)["total"]      # NaN
 
 
-def test_autograd_backward_hands_out_arena_views_and_accumulates_correctly():
-    """loss.backward() through the autograd bridge (notebook/notebook.ipynb:552) no longer clones
-    the 89.7 MB gradient arena: with p.grad None the gradients are views of the arena; when
-    autograd kept such a view (zero_grad(set_to_none=False), or gradient accumulation over two
-    backward passes) the next backward is written to a second arena so accumulation stays
-    correct."""
+@pytest.mark.parametrize("zero_copy", [False, True])
+def test_autograd_backward_accumulates_correctly(zero_copy):
+    """loss.backward() through the autograd bridge (notebook/notebook.ipynb:552): by default the
+    gradients handed to autograd are clones of the arena; with engine.zero_copy_grads they are
+    views of it, and when autograd kept such a view (zero_grad(set_to_none=False), or gradient
+    accumulation over two backward passes) the next backward is written to a second arena so
+    accumulation stays correct."""
     imgs, spds, cmds, tgts = to_dev(*O.synthetic_batch(4, seed=31)[:4])
     mse = torch.nn.functional.mse_loss
 
@@ -874,8 +894,12 @@ def test_autograd_backward_hands_out_arena_views_and_accumulates_correctly():
         return mse(pc, tgts) + 0.05 * mse(ps, spds)
 
     m = make_model().train()
+    m.engine().zero_copy_grads = zero_copy
     loss_of(m).backward()
     eng = m.engine()
+    base = eng.grads.untyped_storage().data_ptr()
+    in_arena = [p.grad.untyped_storage().data_ptr() == base for p in m.parameters()]
+    assert all(in_arena) if zero_copy else not any(in_arena)
     g1 = {n: p.grad.detach().clone() for n, p in m.named_parameters()}
     # second backward WITHOUT zeroing: p.grad must become exactly 2x (same batch, BN statistics
     # do not depend on the running buffers in train mode)
@@ -1383,3 +1407,207 @@ def test_persistent_single_frame_kernel_vs_eager_and_oracle():
     with pytest.raises(RuntimeError):
         pers.eng.run_forward_u8(torch.cat([fr, fr]), torch.tensor([0.3, 0.3], device=dev),
                                 torch.tensor([0, 1], device=dev), persistent=True)
+
+
+def test_autograd_gradients_keep_torch_semantics():
+    """What backward returns stays valid whatever runs next (torch semantics):
+    (1) two forwards of DIFFERENT batch shapes in one graph -- two plans, so the generation check
+        cannot fire; autograd parks the first node's gradients in its input buffer while the
+        second node runs -- must give g(x4) + g(x8), not 2 g(x8);
+    (2) the result of torch.autograd.grad survives a later backward;
+    (3) a saved list of p.grad survives zero_grad(set_to_none=True) + another backward."""
+    mse = torch.nn.functional.mse_loss
+    b4 = to_dev(*O.synthetic_batch(4, seed=41)[:4])
+    b8 = to_dev(*O.synthetic_batch(8, seed=42)[:4])
+
+    def loss_of(m, b):
+        pc, ps = m(b[0], b[1], b[2])
+        return mse(pc, b[3]) + 0.05 * mse(ps, b[1])
+
+    m = make_model().train()
+    params = list(m.parameters())
+    m.zero_grad(set_to_none=True)
+    loss_of(m, b4).backward()
+    g4 = [p.grad.detach().clone() for p in params]
+    m.zero_grad(set_to_none=True)
+    loss_of(m, b8).backward()
+    g8 = [p.grad.detach().clone() for p in params]
+    # (1) both nodes in ONE backward
+    m.zero_grad(set_to_none=True)
+    (loss_of(m, b4) + loss_of(m, b8)).backward()
+    for p, a, b in zip(params, g4, g8):
+        want = a + b
+        assert torch.allclose(p.grad, want, rtol=0, atol=2e-6 * float(want.abs().max() + 1e-30))
+    # (2) autograd.grad result survives a later backward
+    m.zero_grad(set_to_none=True)
+    got = torch.autograd.grad(loss_of(m, b4), params)
+    keep = [g.clone() for g in got]
+    loss_of(m, b8).backward()
+    for g, k, a in zip(got, keep, g4):
+        assert torch.equal(g, k) and torch.equal(g, a)
+    # (3) a saved list of p.grad survives set_to_none + another backward
+    saved = [p.grad for p in params]
+    ref = [g.clone() for g in saved]
+    m.zero_grad(set_to_none=True)
+    loss_of(m, b4).backward()
+    for g, r in zip(saved, ref):
+        assert torch.equal(g, r)
+
+
+# ---- round 3: the noise floor measured instead of assumed ---------------------------------------
+def _conv_indices():
+    """Engine convolution index (parameter order) of every block's conv1 / conv2."""
+    idx, out = 1, []
+    for L, nblk in enumerate((3, 4, 6, 3)):
+        for b in range(nblk):
+            c1, c2 = idx, idx + 1
+            idx += 2
+            if b == 0 and L > 0:
+                idx += 1                      # downsample
+            out.append((c1, c2))
+    return out
+
+
+def _engine_z(eng, pl, conv):
+    """Post-BatchNorm(+residual)+ReLU tensor of convolution `conv` from the plan's workspace, NCHW."""
+    import ctypes as C
+    from cilrs_mi355 import _lib as L
+    yo, zo, n, ch = L.sz(), L.sz(), L.sz(), L.i32()
+    L.check(L.lib().cilrs_net_activation_info(pl.handle, conv, C.byref(yo), C.byref(zo), C.byref(n),
+                                              C.byref(ch)))
+    ws = pl.workspace.view(torch.float32)
+    z = ws[zo.value:zo.value + n.value].view(pl.batch, -1, ch.value)      # [B, H*W, C]
+    return z.permute(0, 2, 1).contiguous().cpu()
+
+
+def test_relu_decisions_at_b128_differ_only_at_rounding_level():
+    """The claim behind the gradient budget: at B = 128 the engine and the
+    fp32 CPU oracle agree on every ReLU decision of the trunk except on a handful of units whose
+    pre-activation is within fp32 rounding of zero -- each of which switches one unit's whole
+    back-propagated gradient in EITHER implementation.  Counted here, per ReLU (32 of them, up to
+    9 M units each): the units on which the two disagree must be few (<= 64 per layer, <= 2e-5 of
+    the layer) and their activation must be at rounding level (<= 1e-5) on the side that kept it."""
+    B = 128
+    imgs, spds, cmds, _, _ = O.synthetic_batch(B, seed=4242)
+    m = make_model().train()
+    eng = m.engine()
+    controls, pred_speed, pl = eng.run_forward(*to_dev(imgs, spds, cmds), True, 0.0, 0)
+    torch.cuda.synchronize()
+    orc = O.build_oracle(0).train()
+    pairs = _conv_indices()
+    stats, seen = [], {}
+
+    def hook_for(bi):
+        def hook(_mod, _inp, out):
+            k = seen.get(bi, 0)
+            seen[bi] = k + 1
+            conv = pairs[bi][k]
+            z_hip = _engine_z(eng, pl, conv).view(out.shape)
+            z_cpu = out.detach()
+            flips = (z_hip > 0) != (z_cpu > 0)
+            n = int(flips.sum())
+            mag = float(torch.maximum(z_hip, z_cpu)[flips].max()) if n else 0.0
+            err = float((z_hip - z_cpu).abs().max())
+            stats.append((conv, n, z_cpu.numel(), mag, err))
+        return hook
+    blocks = [b for layer in list(orc.visual_encoder)[4:8] for b in layer]
+    handles = [b.relu.register_forward_hook(hook_for(i)) for i, b in enumerate(blocks)]
+    with torch.no_grad():
+        orc(imgs, spds, cmds)
+    for h in handles:
+        h.remove()
+    assert len(stats) == 32
+    total = sum(s[1] for s in stats)
+    worst = max(stats, key=lambda s: s[1])
+    print(f"ReLU decisions at B=128: {total} of {sum(s[2] for s in stats)} units differ between the "
+          f"engine and the fp32 oracle; worst layer conv {worst[0]}: {worst[1]} of {worst[2]}; "
+          f"largest activation on a flipped unit {max(s[3] for s in stats):.2e}; "
+          f"max |z_hip - z_cpu| over all layers {max(s[4] for s in stats):.2e}")
+    for conv, n, numel, mag, err in stats:
+        assert n <= max(64, int(2e-5 * numel)), (conv, n, numel)
+        assert mag <= 1e-5, (conv, mag)
+        assert err <= 1e-4, (conv, err)
+
+
+def test_fp32_cpu_realisations_bound_the_gradient_noise():
+    """The floor of the per-tensor gradient gate, measured: the SAME fp32 step computed by four
+    CPU realisations (1 thread / all threads x contiguous / channels_last input) -- all of them
+    'the reference PyTorch CPU path' -- differs from the float64 gradient, and from each other,
+    by what rounding and a few flipped ReLU decisions do.  The engine's error per tensor must be
+    within 2x the WORST of these realisations for that tensor (or within the spread BETWEEN them,
+    whichever is larger): an observed noise level, no constant."""
+    from cilrs_mi355 import CONFIG_A, Trainer
+    from cilrs_mi355.hostinfo import usable_cores
+    ocfg = O.CONFIG_A
+    B = 32
+    imgs, spds, cmds, tgts = O.synthetic_batch(B, seed=777)[:4]
+    g64 = _fp64_grads(ocfg, imgs, spds, cmds, tgts)
+    reals = []
+    for threads in (1, usable_cores()):
+        for cl in (False, True):
+            torch.set_num_threads(threads)
+            o = O.build_oracle(0).train()
+            x = imgs.contiguous(memory_format=torch.channels_last) if cl else imgs
+            pc, ps = o(x, spds, cmds)
+            loss, _ = O.compute_loss(ocfg, pc, tgts, ps, spds)
+            loss.backward()
+            reals.append({n: p.grad.double() for n, p in o.named_parameters()})
+    torch.set_num_threads(usable_cores())
+    tr = Trainer(make_model(), CONFIG_A)
+    eng = tr.eng
+    tr.model.train()
+    c, s_, pl = eng.run_forward(*to_dev(imgs, spds, cmds), True, 0.0, 0)
+    _, dc, dp = tr.loss(c, tgts.cuda(), s_, spds.cuda())
+    eng.run_backward(pl, dc, dp)
+    gv = _grad_views(eng)
+    worst_ratio, rows = 0.0, []
+    for n, ref in g64.items():
+        nrm = max(float(ref.norm()), 1e-30)
+        e_cpu = [float((r[n] - ref).norm()) / nrm for r in reals]
+        spread = max(float((reals[i][n] - reals[j][n]).norm()) / nrm
+                     for i in range(len(reals)) for j in range(i))
+        e_hip = float((gv[n].detach().cpu().double() - ref).norm()) / nrm
+        floor = max(max(e_cpu), spread)
+        rows.append((n, e_hip, max(e_cpu), spread))
+        worst_ratio = max(worst_ratio, e_hip / max(floor, 1e-12))
+        assert e_hip <= 2.0 * floor + 1e-7, (n, e_hip, e_cpu, spread)
+    med = sorted(r[1] for r in rows)[len(rows) // 2]
+    print(f"B={B}: engine per-tensor grad error vs float64: median {med:.2e}, worst "
+          f"{max(r[1] for r in rows):.2e}; worst CPU realisation {max(r[2] for r in rows):.2e}; "
+          f"largest spread between CPU realisations {max(r[3] for r in rows):.2e}; worst "
+          f"engine/floor ratio {worst_ratio:.2f}")
+
+
+def test_validate_matches_the_reference_validate_golden(golden_dir):
+    """tests/golden/validate_cfgB.json was produced by the REFERENCE's own validate()
+    (notebook/notebook.ipynb:563-585) with its CILRSLoss (Config B weights): Trainer.validate on
+    the HIP path must return the same mean-of-batch-means losses and per-command steer MAE."""
+    from cilrs_mi355 import Trainer
+    g = json.load(open(os.path.join(golden_dir, "validate_cfgB.json")))
+    cfg, _ = _cfgs()["B"]
+    tr = Trainer(make_model(), cfg)
+    batches = [to_dev(*O.synthetic_batch(g["batch"], seed=sd)[:4]) for sd in g["seeds"]]
+    got, cmd = tr.validate(batches)
+    for k, v in g["losses"].items():
+        assert abs(got[k] - v) <= 1e-4 * max(1.0, abs(v)), (k, got[k], v)
+    for k, v in g["cmd_steer"].items():
+        if v is None:
+            assert cmd[k] != cmd[k]
+        else:
+            assert abs(cmd[k] - v) <= 1e-4, (k, cmd[k], v)
+
+
+def test_scheduler_step_follows_torch_steplr_for_20_epochs():
+    """Trainer.scheduler_step against torch.optim.lr_scheduler.StepLR(8, 0.5) (nb:535-536, 604),
+    the lr the fused Adam step then uses: 20 epochs, both decays."""
+    from cilrs_mi355 import CONFIG_B, Trainer
+    tr = Trainer(make_model(), CONFIG_B)
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([p], lr=CONFIG_B.lr)
+    sched = torch.optim.lr_scheduler.StepLR(opt, step_size=8, gamma=0.5)
+    for epoch in range(1, 21):
+        assert tr.lr == opt.param_groups[0]["lr"], epoch       # lr used DURING this epoch
+        opt.step()
+        sched.step()
+        tr.scheduler_step()
+    assert tr.epoch == 20 and tr.lr == CONFIG_B.lr * 0.25
