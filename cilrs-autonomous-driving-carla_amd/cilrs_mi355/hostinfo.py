@@ -4,13 +4,12 @@
 job a CPU *share* (16 cores per GPU on this pool): torch / OpenMP pools sized by the affinity mask
 oversubscribe it by an order of magnitude and every CPU-side step (the oracle in the parity tests,
 bench.py's cpu_baseline, the JPEG decode pool) crawls -- the first round-2 GPU call lost its whole
-20-minute budget that way.  `usable_cores()` = min(affinity, cgroup CPU quota, 16 per visible
-GPU), overridable with CILRS_HOST_CORES."""
+20-minute budget that way.  `usable_cores()` = min(affinity, cgroup CPU quota), overridable with
+CILRS_HOST_CORES (no knowledge of a particular pool: the quota is what the job was given; where
+there is no quota the affinity mask is all there is to go by)."""
 from __future__ import annotations
 
 import os
-
-CORES_PER_GPU_SHARE = 16
 
 
 def _cgroup_quota():
@@ -41,14 +40,6 @@ def usable_cores(n_gpus: int | None = None) -> int:
     q = _cgroup_quota()
     if q is not None:
         n = min(n, q)
-    if n_gpus is None:
-        try:
-            import torch
-            n_gpus = torch.cuda.device_count()        # does not initialise the GPU
-        except Exception:
-            n_gpus = 0
-    if n_gpus and n_gpus > 0:
-        n = min(n, CORES_PER_GPU_SHARE * n_gpus)
     return max(1, n)
 
 
@@ -57,5 +48,4 @@ def describe() -> str:
         aff = len(os.sched_getaffinity(0))
     except AttributeError:
         aff = os.cpu_count() or 1
-    return (f"affinity {aff} cores, cgroup quota {_cgroup_quota()}, "
-            f"share {CORES_PER_GPU_SHARE}/GPU -> {usable_cores()} used")
+    return f"affinity {aff} cores, cgroup quota {_cgroup_quota()} -> {usable_cores()} used"

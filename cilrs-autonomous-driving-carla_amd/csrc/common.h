@@ -281,6 +281,28 @@ int launch_conv_small(const ConvSmallArgs& a, hipStream_t s);
 constexpr int kSmallConvBlocks = 256;              // 16x16 tiles up to which it is used
 constexpr int kSmallConvK = 2304;                  // reduction length up to which it is used
 
+// ---- Winograd F(2x2, 3x3) convolution (conv_wino.hip): 3x3 / stride 1 / pad 1 ------------------
+struct WinoArgs {
+    const float* x;          // [N][H][W][C] NHWC (forward: activations; data gradient: dy)
+    const float* U;          // transformed filters [16][C/8][K][8] (launch_wino_weights)
+    float* y;                // [N][H][W][K]
+    const float* addend;     // optional, y's layout: y = conv + addend
+    int N, H, W, C, K;
+    float* bn_partial;       // optional: BatchNorm batch statistics of the output, per-block column
+                             // partials [2][K][wino_groups] (sum | sum of squares)
+    // optional (data gradient): BatchNorm-backward reductions of the layer this output feeds,
+    // [2][K][wino_groups] partials of g and g * xhat (as ConvArgs::bwd_*)
+    const float* bwd_z; const float* bwd_y; const float* bwd_stats; int bwd_relu;
+    float* bwd_partial;
+};
+size_t wino_weight_floats(int K, int C);
+// U from OHWI weights w[K][3][3][C]; dgrad = 1: the filter of the data gradient (taps flipped,
+// channel roles swapped: reduction over K, C output channels)
+int launch_wino_weights(const float* w, float* U, int K, int C, int dgrad, hipStream_t s);
+bool wino_supported(int C, int K, int ksize, int stride, int pad);
+int wino_groups(int N, int H, int W);        // column-partial rows a launch writes
+int launch_conv_wino(const WinoArgs& a, hipStream_t s);
+
 // ---- persistent single-frame inference kernel (infer_b1.hip) ---------------------------------
 // The whole eval forward of ONE frame (reference control loop, model/autonomous_drive.py:908-920)
 // as ONE launch: one 1,024-thread workgroup per CU walks a table of stages (preprocess, stem,

@@ -2318,6 +2318,49 @@ int cilrs_conv2d_wgrad_16(const float* x, const float* dy, float* dw, float* scr
         make_wgrad16(x16, dy16, dw, scratch32, N, H, W, Cin, Cout, K, stride, pad, bf16), s);
 }
 
+// Winograd F(2x2,3x3) forms of the two operators above (3x3 / stride 1 / pad 1): filter transform
+// + fused convolution.  scratch: cilrs_conv2d_wino_scratch_floats(Cin, Cout) floats.
+size_t cilrs_conv2d_wino_scratch_floats(int Cin, int Cout) { return wino_weight_floats(Cout, Cin); }
+
+int cilrs_conv2d_wino_fwd(const float* x, const float* w, float* y, int N, int H, int W, int Cin,
+                          int Cout, float* scratch, void* stream) {
+    CILRS_CHECK(x && w && y && scratch, "conv2d_wino_fwd: NULL argument");
+    CILRS_CHECK(wino_supported(Cin, Cout, 3, 1, 1), "conv2d_wino_fwd: Cin %% 8, Cout %% 64");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (launch_wino_weights(w, scratch, Cout, Cin, 0, s)) return 1;
+    WinoArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.U = scratch; a.y = y; a.N = N; a.H = H; a.W = W; a.C = Cin; a.K = Cout;
+    return launch_conv_wino(a, s);
+}
+
+int cilrs_wino_filter_transform(const float* w, float* U, int Cin, int Cout, int dgrad, void* stream) {
+    CILRS_CHECK(w && U, "wino_filter_transform: NULL argument");
+    return launch_wino_weights(w, U, Cout, Cin, dgrad, reinterpret_cast<hipStream_t>(stream));
+}
+
+int cilrs_conv2d_wino_pre(const float* x, const float* U, float* y, const float* addend, int N, int H,
+                          int W, int Cred, int Cout, void* stream) {
+    CILRS_CHECK(x && U && y, "conv2d_wino_pre: NULL argument");
+    WinoArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.U = U; a.y = y; a.addend = addend; a.N = N; a.H = H; a.W = W; a.C = Cred; a.K = Cout;
+    return launch_conv_wino(a, reinterpret_cast<hipStream_t>(stream));
+}
+
+int cilrs_conv2d_wino_dgrad(const float* dy, const float* w, float* dx, const float* addend, int N,
+                            int H, int W, int Cin, int Cout, float* scratch, void* stream) {
+    CILRS_CHECK(dy && w && dx && scratch, "conv2d_wino_dgrad: NULL argument");
+    CILRS_CHECK(wino_supported(Cout, Cin, 3, 1, 1), "conv2d_wino_dgrad: Cout %% 8, Cin %% 64");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (launch_wino_weights(w, scratch, Cout, Cin, 1, s)) return 1;
+    WinoArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = dy; a.U = scratch; a.y = dx; a.addend = addend;
+    a.N = N; a.H = H; a.W = W; a.C = Cout; a.K = Cin;
+    return launch_conv_wino(a, s);
+}
+
 size_t cilrs_bn_partial_floats(int C) { return bn_partial_floats(C); }
 
 int cilrs_bn_train_fwd(const float* y, int M, int C, const float* gamma, const float* beta,

@@ -355,6 +355,23 @@ int cilrs_conv2d_wgrad_16(const float* x, const float* dy, float* dw, float* scr
                           int H, int W, int Cin, int Cout, int K, int stride, int pad, int bf16,
                           void* scratch16, void* stream);
 /* nn.BatchNorm2d training forward (+ optional residual add, ReLU); stats: 4*C floats out */
+/* The same 3x3 / stride 1 / pad 1 convolution (nn.Conv2d(C, K, 3, 1, 1, bias=False) of
+ * torchvision's BasicBlock: conv1 of every non-first block and every conv2) and its data gradient
+ * by Winograd F(2x2, 3x3) on the fp32 matrix pipe: 16 multiplications per 2x2 output tile and
+ * channel instead of 36.  fp32 throughout; results differ from the direct sum by rounding
+ * (a few 1e-6 relative).  w: OHWI like everywhere; scratch: transformed filters,
+ * cilrs_conv2d_wino_scratch_floats(Cin, Cout) floats.  Cin %% 8 == 0, Cout %% 64 == 0 (dgrad: the
+ * roles swap). */
+size_t cilrs_conv2d_wino_scratch_floats(int Cin, int Cout);
+int cilrs_conv2d_wino_fwd(const float* x, const float* w, float* y, int N, int H, int W, int Cin,
+                          int Cout, float* scratch, void* stream);
+/* the two halves on their own: U = transformed filters ([16][Cred/8][Cout][8]; dgrad = 1: the
+ * data gradient's filter, reduction over the forward Cout), and the convolution on a ready U */
+int cilrs_wino_filter_transform(const float* w, float* U, int Cin, int Cout, int dgrad, void* stream);
+int cilrs_conv2d_wino_pre(const float* x, const float* U, float* y, const float* addend, int N, int H,
+                          int W, int Cred, int Cout, void* stream);
+int cilrs_conv2d_wino_dgrad(const float* dy, const float* w, float* dx, const float* addend, int N,
+                            int H, int W, int Cin, int Cout, float* scratch, void* stream);
 size_t cilrs_bn_partial_floats(int C);
 int cilrs_bn_train_fwd(const float* y, int M, int C, const float* gamma, const float* beta,
                        float* running_mean, float* running_var, int64_t* nbt, float momentum,

@@ -591,3 +591,54 @@ def test_conv16_fwd_dgrad_wgrad(case, bf16):
     want = gw.permute(0, 2, 3, 1)
     assert torch.isfinite(dw).all()
     assert (dw.cpu().double() - want).abs().max() <= 5e-5 * float(want.abs().max())
+
+
+# ---- Winograd F(2x2, 3x3) forms of the 3x3 / stride 1 / pad 1 convolution ------------------------
+WINO_CASES = [
+    (3, 22, 50, 64, 64),       # layer1
+    (3, 11, 25, 128, 128),     # layer2 (odd height and width: half-filled edge tiles)
+    (5, 6, 13, 256, 256),      # layer3
+    (7, 3, 7, 512, 512),       # layer4
+    (1, 5, 3, 8, 64),          # fewer tiles than a block, one reduction chunk
+    (128, 22, 50, 64, 64),     # the benchmark batch, layer1
+    (128, 11, 25, 128, 128),   # the benchmark batch, layer2
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES)
+def test_conv_wino_fwd_and_dgrad(case):
+    """Winograd F(2x2,3x3) against torch's fp32 CPU convolution and its autograd.  fp32 Winograd
+    rounds at other points than the direct sum (filter transform with halves, 4x4 transform-domain
+    sums): tolerance 5e-5 of max|ref| (the direct kernels sit at 2e-5; the contract is 1e-4)."""
+    L = _lib()
+    lib = L.lib()
+    N, H, W, Cin, Cout = case
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5
+    x.requires_grad_(True)
+    torch.set_num_threads(16)
+    ref = F.conv2d(x, w, None, 1, 1)
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy)
+    add = torch.randn(N, Cin, H, W, generator=g)
+    xd, wd = nhwc(x.detach()), ohwi(w)
+    y = torch.full((N, H, W, Cout), float("nan"), device="cuda")
+    scratch = torch.empty(lib.cilrs_conv2d_wino_scratch_floats(Cin, Cout), device="cuda")
+    L.check(lib.cilrs_conv2d_wino_fwd(L.ptr(xd), L.ptr(wd), L.ptr(y), N, H, W, Cin, Cout,
+                                      L.ptr(scratch), stream()))
+    torch.cuda.synchronize()
+    got = y.cpu().permute(0, 3, 1, 2)
+    assert torch.isfinite(got).all()
+    err = float((got - ref.detach()).abs().max())
+    assert err <= _tol(ref.detach(), 5e-5), err
+    if Cin % 64 == 0:
+        dx = torch.full((N, H, W, Cin), float("nan"), device="cuda")
+        dyd, addd = nhwc(dy), nhwc(add)              # (kept alive across the launch)
+        L.check(lib.cilrs_conv2d_wino_dgrad(L.ptr(dyd), L.ptr(wd), L.ptr(dx), L.ptr(addd),
+                                            N, H, W, Cin, Cout, L.ptr(scratch), stream()))
+        torch.cuda.synchronize()
+        gdx = dx.cpu().permute(0, 3, 1, 2)
+        want = x.grad + add
+        assert torch.isfinite(gdx).all()
+        assert float((gdx - want).abs().max()) <= _tol(want, 5e-5)
