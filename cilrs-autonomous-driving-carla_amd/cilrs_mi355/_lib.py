@@ -72,6 +72,7 @@ SIGNATURES = {
     "cilrs_net_forward_u8_b1": (i32, [vp, C.POINTER(Buffers), vp, vp, vp, vp, vp, vp]),
     "cilrs_net_forward_camera_b1": (i32, [vp, C.POINTER(Buffers), vp, i32, i32, i32, C.c_long, vp, vp,
                                           vp, vp, i32, vp]),
+    "cilrs_net_forward_u8_b1_post": (i32, [vp, C.POINTER(Buffers), vp, vp, vp, vp, vp, vp, i32, vp]),
     "cilrs_net_forward_u8_b1_sync": (i32, [vp, C.POINTER(Buffers), vp, vp, vp, vp, vp, vp]),
     "cilrs_net_b1_stages": (i32, [vp]),
     "cilrs_net_b1_stage_us": (i32, [vp, C.POINTER(Buffers), c_float_p, c_float_p, i32]),

@@ -61,15 +61,21 @@ class Predictor:
         self.frames_host, self.speed_host, self.cmd_host = views(self.in_host)
         self.frames_dev, self.speed_dev, self.cmd_dev = views(self.in_dev)
         self.out_dev = torch.empty(batch * 4, dtype=torch.float32, device=dev)
-        self.out_host = torch.empty(batch * 4, dtype=torch.float32).pin_memory()
+        # [controls | predicted speed | completion word of the persistent launch]
+        self.out_host = torch.zeros(batch * 4 + 4, dtype=torch.float32).pin_memory()
         self.ctrl_dev = self.out_dev[:batch * 3].view(batch, 3)
         self.spd_out_dev = self.out_dev[batch * 3:]
         self._ctrl_host = self.out_host[:batch * 3].view(batch, 3)
-        self._spd_host = self.out_host[batch * 3:]
+        self._spd_host = self.out_host[batch * 3:batch * 4]
+        self._done_host = self.out_host[batch * 4:batch * 4 + 1].view(torch.int32)
+        self._done_np = self._done_host.numpy()
+        self._seq = 0
+        # CILRS_B1_SPIN=0: wait with hipStreamSynchronize instead of spinning on the completion word
+        self.spin = os.environ.get("CILRS_B1_SPIN", "1") != "0"
         # CILRS_B1_ZERO_COPY=0: stage through device buffers (A/B switch of tools/infer_b1_probe.py)
         self.zero_copy = os.environ.get("CILRS_B1_ZERO_COPY", "1") != "0"
         self._ctrl_np = self.out_host[:batch * 3].view(batch, 3).numpy()
-        self._spd_np = self.out_host[batch * 3:].numpy()
+        self._spd_np = self.out_host[batch * 3:batch * 4].numpy()
         self._frames_np = self.frames_host.numpy()
         self._speed_np = self.speed_host.numpy()
         self._cmd_np = self.cmd_host.numpy()
@@ -128,7 +134,7 @@ class Predictor:
                 self.eng.run_forward_u8(self.frames_dev, self.speed_dev, self.cmd_dev,
                                         out=(self.ctrl_dev, self.spd_out_dev), graph=self.use_graph,
                                         half=self.half, persistent=self.persistent)
-                self.out_host.copy_(self.out_dev, non_blocking=True)     # pinned; no torch kernels
+                self.out_host[:self.batch * 4].copy_(self.out_dev, non_blocking=True)   # pinned; no torch kernels
                 self.stream.synchronize()
         if self.persistent and not np.isfinite(self._ctrl_np).all():
             self.eng.check_status()       # a grid barrier that gave up leaves NaN outputs
@@ -156,8 +162,22 @@ class Predictor:
             fast = self._fast = (L.lib().cilrs_net_forward_u8_b1_sync, pl.handle, _C.byref(pl.bufs),
                                  L.ptr(self.frames_host), L.ptr(self.speed_host),
                                  L.ptr(self.cmd_host), L.ptr(self._ctrl_host), L.ptr(self._spd_host),
-                                 _C.c_void_p(self.stream.cuda_stream), pl)
-        if fast[0](*fast[1:9]) != 0:
+                                 _C.c_void_p(self.stream.cuda_stream), pl,
+                                 L.lib().cilrs_net_forward_u8_b1_post, L.ptr(self._done_host))
+        if self.spin:
+            # the launch posts its own completion word behind the outputs: spin on it instead of
+            # waiting for the stream's completion signal
+            self._seq = seq = (self._seq % 0x3FFFFFFF) + 1
+            if fast[10](fast[1], fast[2], fast[3], fast[4], fast[5], fast[6], fast[7], fast[11], seq,
+                        fast[8]) != 0:
+                _L.check(1)
+            done, n = self._done_np, 0
+            while done[0] != seq:
+                n += 1
+                if n > 2000000:             # ~seconds: something is wrong; let the stream tell us
+                    self.stream.synchronize()
+                    break
+        elif fast[0](*fast[1:9]) != 0:
             _L.check(1)
         if not np.isfinite(self._ctrl_np).all():
             eng.check_status()            # a grid barrier that gave up leaves NaN outputs
@@ -224,7 +244,7 @@ class Predictor:
             self.eng.run_forward_camera(cam[2][1], cam[2][2], cam[2][3],
                                         self.frames_host.size(1), self.frames_host.size(2),
                                         out=(self.ctrl_dev, self.spd_out_dev))
-            self.out_host.copy_(self.out_dev, non_blocking=True)
+            self.out_host[:self.batch * 4].copy_(self.out_dev, non_blocking=True)
             self.stream.synchronize()
         c = self._ctrl_np[0]
         return (float(c[0]), float(c[1]), float(c[2]), float(self._spd_np[0]) * SPEED_NORM_FACTOR)

@@ -357,6 +357,8 @@ struct B1Launch {
     float* controls; float* pred_speed;
     int* sync;                              // kB1SyncInts ints, zeroed once
     int* status;                            // [0] bad command, [1] grid barrier gave up
+    int* done; int seq;                     // optional: word (pinned host memory) that receives `seq`
+                                            // right after the outputs are written
     long long* stamps;                      // optional [2][kB1MaxStages + 1]: block 0's 100 MHz clock at
                                             // every stage start / work end (diagnostics; NULL = off)
     float mean[3], stdv[3];

@@ -647,7 +647,11 @@ __device__ __forceinline__ void head_stage(const B1Stage* st, const B1Launch& a,
     const int out0 = RFL(h->out[0]), out1 = RFL(h->out[1]);
     const int relu = RFL(h->relu);
     bool stored = false;
-    for (int slot = wave * nblk + blockIdx.x; slot < out0 + out1; slot += 16 * nblk) {
+    // the last layer (3 + 1 outputs) stays in block 0, so that its thread 0 can post the tick's
+    // completion word right behind the outputs
+    const int slot0 = last ? (blockIdx.x == 0 ? wave : out0 + out1) : wave * nblk + (int)blockIdx.x;
+    const int slot_step = last ? out0 + out1 : 16 * nblk;
+    for (int slot = slot0; slot < out0 + out1; slot += slot_step) {
         const int chain = slot >= out0 ? 1 : 0;
         const int o = chain ? slot - out0 : slot;
         const int in = chain ? in1 : in0;
@@ -689,6 +693,17 @@ __device__ __forceinline__ void head_stage(const B1Stage* st, const B1Launch& a,
         }
     }
     if (stored) drain_stores();
+    if (last && blockIdx.x == 0 && a.done != nullptr) {
+        // Completion word for a host that spins on pinned memory instead of waiting for the
+        // stream: the four outputs are drained first (they may be in HOST memory: stores from
+        // four waves), then ONE store of this tick's sequence number.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            // (writes of one device to one host buffer arrive in order)
+            __hip_atomic_store(a.done, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 __device__ __forceinline__ unsigned desc_stage_cmd_off(const B1Stage* table) { return table[0].cmd_off; }
@@ -794,6 +809,10 @@ __global__ __launch_bounds__(kThreads) void infer_b1_kernel(const B1Launch a) {
         if (*reinterpret_cast<volatile int*>(&fail)) {
             const float nan = __builtin_nanf("");
             a.controls[0] = nan; a.controls[1] = nan; a.controls[2] = nan; a.pred_speed[0] = nan;
+            if (a.done != nullptr) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(a.done, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     }
 }

@@ -1586,7 +1586,7 @@ static int b1_build(cilrs_net* net, int nblk) {
 
 static int b1_launch(cilrs_net* net, const cilrs_buffers* bufs, const uint8_t* frame,
                      int first_stage, const float* speed, const int64_t* command, float* controls,
-                     float* pred_speed, void* stream) {
+                     float* pred_speed, void* stream, int* done = nullptr, int seq = 0) {
     if (check_bufs(net, bufs, false)) return 1;
     CILRS_CHECK((frame || first_stage == 1) && speed && command && controls && pred_speed,
                 "forward_u8_b1: NULL tensor");
@@ -1616,6 +1616,7 @@ static int b1_launch(cilrs_net* net, const cilrs_buffers* bufs, const uint8_t* f
     a.first_stage = first_stage;
     a.ws = ws; a.ws_bytes = net->ws_bytes;
     a.params = bufs->params; a.param_bytes = net->A->arena_floats * sizeof(float);
+    a.done = done; a.seq = seq;
     a.frame = frame; a.speed = speed; a.cmd = reinterpret_cast<const long long*>(command);
     a.controls = controls; a.pred_speed = pred_speed;
     a.sync = reinterpret_cast<int*>(ws + net->b1_sync);
@@ -1652,6 +1653,13 @@ int cilrs_net_forward_camera_b1(cilrs_net* net, const cilrs_buffers* bufs, const
     if (b1_launch(net, bufs, nullptr, 1, speed, command, controls, pred_speed, stream)) return 1;
     if (sync) CILRS_HIP(hipStreamSynchronize(s));
     return 0;
+}
+
+int cilrs_net_forward_u8_b1_post(cilrs_net* net, const cilrs_buffers* bufs, const uint8_t* frame,
+                                 const float* speed, const int64_t* command, float* controls,
+                                 float* pred_speed, int* done, int seq, void* stream) {
+    CILRS_CHECK(done != nullptr, "forward_u8_b1_post: NULL completion word");
+    return b1_launch(net, bufs, frame, 0, speed, command, controls, pred_speed, stream, done, seq);
 }
 
 int cilrs_net_forward_u8_b1_sync(cilrs_net* net, const cilrs_buffers* bufs, const uint8_t* frame,
@@ -1691,6 +1699,11 @@ int cilrs_net_b1_stage_us(cilrs_net* net, const cilrs_buffers* bufs, float* star
             for (int b = 0; b < nb; ++b) if (t[b] > t[worst]) worst = b;
             fprintf(stderr, "stage %2d done: min %5.2f p50 %5.2f p90 %5.2f max %5.2f (block %d; block 0 %5.2f)\n",
                     i, srt[0], srt[nb / 2], srt[nb * 9 / 10], srt[nb - 1], worst, t[0]);
+            if (getenv("CILRS_B1_DUMP") && (i == 4 || i == 12 || i == 20 || i == 32)) {
+                fprintf(stderr, "stage %2d per block:", i);
+                for (int b = 0; b < nb; ++b) fprintf(stderr, " %.2f", t[b]);
+                fprintf(stderr, "\n");
+            }
         }
     }
     if (getenv("CILRS_B1_FINE"))           // conv stages: block 0 / wave 0 inside the stage

@@ -210,6 +210,14 @@ int cilrs_net_forward_camera_b1(cilrs_net* net, const cilrs_buffers* bufs, const
                                 int src_h, int src_w, int pixel_stride, long row_stride,
                                 const float* speed, const int64_t* command, float* controls,
                                 float* pred_speed, int sync, void* stream);
+/* ... that posts its completion itself: right after the four outputs the launch stores `seq` into
+ * `done` (a word of pinned host memory next to the outputs).  A control loop that keeps frame,
+ * outputs and this word in ONE pinned buffer launches, spins on the word and reads the outputs --
+ * no stream synchronisation on the tick's critical path (it saves the completion-signal and
+ * wake-up latency, ~10 us of a ~0.3 ms tick).  The launch still completes on `stream` as usual. */
+int cilrs_net_forward_u8_b1_post(cilrs_net* net, const cilrs_buffers* bufs, const uint8_t* frame,
+                                 const float* speed, const int64_t* command, float* controls,
+                                 float* pred_speed, int* done, int seq, void* stream);
 /* ... followed by hipStreamSynchronize(stream): one library call per control-loop tick when the
  * frame / speed / command and the outputs live in pinned host memory (the kernel reads and writes
  * them in place; no copy commands). */
