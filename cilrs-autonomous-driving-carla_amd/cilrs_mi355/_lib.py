@@ -107,6 +107,7 @@ SIGNATURES = {
     "cilrs_conv2d_wino_scratch_floats": (sz, [i32, i32]),
     "cilrs_conv2d_wino_fwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
     "cilrs_wino_filter_transform": (i32, [vp, vp, i32, i32, i32, vp]),
+    "cilrs_conv2d_wino_stamps": (i32, [vp]),
     "cilrs_conv2d_wino_pre": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "cilrs_conv2d_wino_dgrad": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
     "cilrs_bn_partial_floats": (sz, [i32]),

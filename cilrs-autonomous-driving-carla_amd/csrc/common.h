@@ -294,6 +294,7 @@ struct WinoArgs {
     // [2][K][wino_groups] partials of g and g * xhat (as ConvArgs::bwd_*)
     const float* bwd_z; const float* bwd_y; const float* bwd_stats; int bwd_relu;
     float* bwd_partial;
+    long long* stamps;       // diagnostics: block 0's waves 0 / 4 write 2 x 8 cycle counts (NULL: off)
 };
 size_t wino_weight_floats(int K, int C);
 // U from OHWI weights w[K][3][3][C]; dgrad = 1: the filter of the data gradient (taps flipped,

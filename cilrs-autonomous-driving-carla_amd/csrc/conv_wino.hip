@@ -18,8 +18,9 @@
 // Block = 512 threads (8 waves, one block per CU); tile = 64 output tiles (2x2 pixels each) x 64
 // output channels x all 16 xi; wave w owns xi = 2w, 2w+1 for the whole tile (128 accumulator
 // registers: 2 xi x 2x2 sub-tiles of 32x32); reduction in chunks of 8 input channels:
-//   * gather + transform: thread = (tile, channel): 16 buffer loads (a patch pixel outside the
-//     image gets the offset ~0 = out of range = zeros), 32 additions, 16 LDS stores;
+//   * gather + transform: four waves (one per SIMD), thread = (tile, channel pair): 16 8-byte
+//     buffer loads (a patch pixel outside the image gets the offset ~0 = out of range = zeros),
+//     32 packed additions, 16 8-byte LDS stores;
 //   * U chunk: 32 KB, contiguous 2 KB per xi;  both are fetched one chunk ahead into registers;
 //   * multiply: per xi two A and two B fragments (ds_read_b128), 16 v_mfma_f32_32x32x2_f32; two
 //     LDS stages, one barrier per chunk;
@@ -104,12 +105,14 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
     const int k0 = blk_n * WK;
     const int nchunks = a.C / WC;
 
-    // ---- gather role: this thread's (tile, channel) and the 16 patch pixels ----
-    const int g_tile = tid >> 3, g_c = tid & 7;
+    // ---- gather role (waves 0-3, one per SIMD): this thread's (tile, channel PAIR) and the 16
+    //      patch pixels; 8-byte loads, packed additions, 8-byte LDS stores ----
+    const bool gatherer = tid < 256;
+    const int g_tile = (tid >> 2) & 63, g_p = tid & 3;
     unsigned voff[16];
     {
         const int t = blk_m * WT + g_tile;
-        const bool tv = t < total_tiles;
+        const bool tv = t < total_tiles && gatherer;
         const int n = tv ? t / tiles_img : 0, rem = t - n * tiles_img;
         const int ty = rem / TW, tx = rem - ty * TW;
         const int h0 = 2 * ty - 1, w0 = 2 * tx - 1;
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
         for (int p = 0; p < 16; ++p) {
             const int h = h0 + (p >> 2), w = w0 + (p & 3);
             const bool ok = tv && h >= 0 && w >= 0 && h < a.H && w < a.W;
-            voff[p] = ok ? (unsigned)((((n * a.H + h) * a.W + w) * a.C + g_c) * 4) : 0xFFFFFFFFu;
+            voff[p] = ok ? (unsigned)((((n * a.H + h) * a.W + w) * a.C + g_p * 2) * 4) : 0xFFFFFFFFu;
         }
     }
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(
@@ -129,20 +132,23 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
     const int u_idx = tid & 127, u_xi0 = tid >> 7;
     const unsigned u_lds = (unsigned)((u_idx >> 1) * WP + (u_idx & 1) * 4);
 
-    float d[16];
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 d[16];
     f32x4 ur[4];
     auto load_chunk = [&](const int ch) {
         if (CILRS_WINO_DBG & 1) {
 #pragma unroll
-            for (int p = 0; p < 16; ++p) d[p] = (float)(p + ch);
+            for (int p = 0; p < 16; ++p) d[p] = f32x2{(float)(p + ch), 1.f};
 #pragma unroll
             for (int q = 0; q < 4; ++q) ur[q] = f32x4{1.f, 2.f, 3.f, (float)ch};
             return;
         }
         const int soff = ch * WC * 4;
+        if (gatherer) {
 #pragma unroll
-        for (int p = 0; p < 16; ++p)
-            d[p] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsX, (int)voff[p], soff, 0));
+            for (int p = 0; p < 16; ++p)
+                d[p] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsX, (int)voff[p], soff, 0));
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int xi = q * 4 + u_xi0;
@@ -156,25 +162,27 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
             return;
         }
         // V = B^T d B;  B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]
-        float r[16];
+        if (gatherer) {
+            f32x2 r[16];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            r[0 * 4 + j] = d[0 * 4 + j] - d[2 * 4 + j];
-            r[1 * 4 + j] = d[1 * 4 + j] + d[2 * 4 + j];
-            r[2 * 4 + j] = d[2 * 4 + j] - d[1 * 4 + j];
-            r[3 * 4 + j] = d[1 * 4 + j] - d[3 * 4 + j];
-        }
+            for (int j = 0; j < 4; ++j) {
+                r[0 * 4 + j] = d[0 * 4 + j] - d[2 * 4 + j];
+                r[1 * 4 + j] = d[1 * 4 + j] + d[2 * 4 + j];
+                r[2 * 4 + j] = d[2 * 4 + j] - d[1 * 4 + j];
+                r[3 * 4 + j] = d[1 * 4 + j] - d[3 * 4 + j];
+            }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float v0 = r[i * 4 + 0] - r[i * 4 + 2];
-            const float v1 = r[i * 4 + 1] + r[i * 4 + 2];
-            const float v2 = r[i * 4 + 2] - r[i * 4 + 1];
-            const float v3 = r[i * 4 + 1] - r[i * 4 + 3];
-            float* dst = Vs + stage * STAGE + (i * 4) * (WT * WP) + g_tile * WP + g_c;
-            dst[0 * WT * WP] = v0;
-            dst[1 * WT * WP] = v1;
-            dst[2 * WT * WP] = v2;
-            dst[3 * WT * WP] = v3;
+            for (int i = 0; i < 4; ++i) {
+                const f32x2 v0 = r[i * 4 + 0] - r[i * 4 + 2];
+                const f32x2 v1 = r[i * 4 + 1] + r[i * 4 + 2];
+                const f32x2 v2 = r[i * 4 + 2] - r[i * 4 + 1];
+                const f32x2 v3 = r[i * 4 + 1] - r[i * 4 + 3];
+                float* dst = Vs + stage * STAGE + (i * 4) * (WT * WP) + g_tile * WP + g_p * 2;
+                *reinterpret_cast<f32x2*>(dst + 0 * WT * WP) = v0;
+                *reinterpret_cast<f32x2*>(dst + 1 * WT * WP) = v1;
+                *reinterpret_cast<f32x2*>(dst + 2 * WT * WP) = v2;
+                *reinterpret_cast<f32x2*>(dst + 3 * WT * WP) = v3;
+            }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -195,6 +203,7 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
     // already on its way from global memory (registers) and is transformed and stored into the
     // other stage right behind the multiplies -- ONE barrier per chunk, and the waves of a SIMD
     // drift apart so that one's LDS stores run under the other's MFMAs.
+    const long long tm_start = (a.stamps != nullptr && blockIdx.x == 0) ? __builtin_amdgcn_s_memtime() : 0;
     load_chunk(0);
     store_chunk(0);
     if (nchunks > 1) load_chunk(1);
@@ -236,18 +245,36 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
             if (ch + 2 < nchunks) load_chunk(ch + 2);
         }
     };
+    // diagnostics (WinoArgs::stamps, tools/wino_bench.py): where block 0's waves 0 and 4 spend a
+    // launch, in shader cycles: [prologue, multiply, refill, barrier wait, epilogue]
+    long long tm_mul = 0, tm_ref = 0, tm_bar = 0;
+    const bool stamp = a.stamps != nullptr && blockIdx.x == 0 && (tid == 0 || tid == 256);
+    const long long tm0 = tm_start;
+    long long tm_loop0 = 0;
+    if (stamp) tm_loop0 = __builtin_amdgcn_s_memtime();
     for (int ch = 0; ch < nchunks; ++ch) {
+        long long ta = 0, tb = 0, tc = 0, td = 0;
+        if (stamp) ta = __builtin_amdgcn_s_memtime();
         if (late) {
             refill(ch);
             __builtin_amdgcn_sched_barrier(0);
+            if (stamp) tb = __builtin_amdgcn_s_memtime();
             multiply(ch);
         } else {
             multiply(ch);
             __builtin_amdgcn_sched_barrier(0);
+            if (stamp) tb = __builtin_amdgcn_s_memtime();
             refill(ch);
         }
+        if (stamp) tc = __builtin_amdgcn_s_memtime();
         __syncthreads();
+        if (stamp) {
+            td = __builtin_amdgcn_s_memtime();
+            if (late) { tm_ref += tb - ta; tm_mul += tc - tb; } else { tm_mul += tb - ta; tm_ref += tc - tb; }
+            tm_bar += td - tc;
+        }
     }
+    const long long tm_loop1 = stamp ? __builtin_amdgcn_s_memtime() : 0;
 
     if (CILRS_WINO_DBG & 8) {
         if (acc[0][0][0][0] == 123.f) a.y[tid] = acc[1][1][1][3];
@@ -320,6 +347,11 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
             }
             __syncthreads();
         }
+    }
+    if (stamp) {
+        long long* o = a.stamps + (tid == 0 ? 0 : 8);
+        o[0] = tm_loop0 - tm0; o[1] = tm_mul; o[2] = tm_ref; o[3] = tm_bar;
+        o[4] = __builtin_amdgcn_s_memtime() - tm_loop1; o[5] = tm_loop1 - tm_loop0;
     }
     // column partials of this block: [2][K][groups] like the implicit-GEMM kernel's (channel-major),
     // threads with equal e_col (16 of them) summed in fixed order

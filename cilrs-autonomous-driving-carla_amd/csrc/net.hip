@@ -2347,6 +2347,9 @@ int cilrs_conv2d_wino_fwd(const float* x, const float* w, float* y, int N, int H
     return launch_conv_wino(a, s);
 }
 
+static long long* g_wino_stamps = nullptr;
+int cilrs_conv2d_wino_stamps(long long* stamps16) { g_wino_stamps = stamps16; return 0; }
+
 int cilrs_wino_filter_transform(const float* w, float* U, int Cin, int Cout, int dgrad, void* stream) {
     CILRS_CHECK(w && U, "wino_filter_transform: NULL argument");
     return launch_wino_weights(w, U, Cout, Cin, dgrad, reinterpret_cast<hipStream_t>(stream));
@@ -2358,6 +2361,7 @@ int cilrs_conv2d_wino_pre(const float* x, const float* U, float* y, const float*
     WinoArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x; a.U = U; a.y = y; a.addend = addend; a.N = N; a.H = H; a.W = W; a.C = Cred; a.K = Cout;
+    a.stamps = g_wino_stamps;        // diagnostics: cilrs_conv2d_wino_stamps (tools/wino_bench.py)
     return launch_conv_wino(a, reinterpret_cast<hipStream_t>(stream));
 }
 

@@ -376,6 +376,10 @@ int cilrs_conv2d_wino_fwd(const float* x, const float* w, float* y, int N, int H
 /* the two halves on their own: U = transformed filters ([16][Cred/8][Cout][8]; dgrad = 1: the
  * data gradient's filter, reduction over the forward Cout), and the convolution on a ready U */
 int cilrs_wino_filter_transform(const float* w, float* U, int Cin, int Cout, int dgrad, void* stream);
+/* diagnostics: 16 int64 device words that block 0's waves 0 and 4 of every later
+ * cilrs_conv2d_wino_pre launch fill with shader-cycle counts [prologue, multiply, refill, barrier
+ * wait, epilogue, K loop] (NULL: off) */
+int cilrs_conv2d_wino_stamps(long long* stamps16);
 int cilrs_conv2d_wino_pre(const float* x, const float* U, float* y, const float* addend, int N, int H,
                           int W, int Cred, int Cout, void* stream);
 int cilrs_conv2d_wino_dgrad(const float* dy, const float* w, float* dx, const float* addend, int N,

@@ -40,8 +40,6 @@ for name, H, W, Cc in (("layer1", 22, 50, 64), ("layer2", 11, 25, 128), ("layer3
         L.check(lib.cilrs_conv2d_fwd(L.ptr(x), L.ptr(w), L.ptr(y), N, H, W, Cc, Cc, 3, 3, 1, 1, -1, 0,
                                      L.ptr(scratch), scratch.numel(), st))
 
-    def wino():
-        L.check(lib.cilrs_conv2d_wino_fwd(L.ptr(x), L.ptr(w), L.ptr(y), N, H, W, Cc, Cc, L.ptr(scratch), st))
     def wino_pre():
         L.check(lib.cilrs_conv2d_wino_pre(L.ptr(x), L.ptr(scratch), L.ptr(y), None, N, H, W, Cc, Cc, st))
 
@@ -50,7 +48,19 @@ for name, H, W, Cc in (("layer1", 22, 50, 64), ("layer2", 11, 25, 128), ("layer3
 
     def filt_d():
         L.check(lib.cilrs_wino_filter_transform(L.ptr(w), L.ptr(scratch), Cc, Cc, 1, st))
+
+    def wino():
+        L.check(lib.cilrs_conv2d_wino_fwd(L.ptr(x), L.ptr(w), L.ptr(y), N, H, W, Cc, Cc, L.ptr(scratch), st))
     t_i, t_w = timed(igemm), timed(wino)
+    if os.environ.get("WINO_STAMPS"):
+        stamps = torch.zeros(16, dtype=torch.int64, device="cuda")
+        lib.cilrs_conv2d_wino_stamps(L.ptr(stamps))
+        filt(); wino_pre(); torch.cuda.synchronize()
+        lib.cilrs_conv2d_wino_stamps(None)
+        v = stamps.cpu().tolist()
+        for wn, o in (("wave 0 (multiply first)", 0), ("wave 4 (refill first)", 8)):
+            print(f"   block 0 {wn}: prologue {v[o]} multiply {v[o+1]} refill {v[o+2]} barrier wait {v[o+3]} "
+                  f"epilogue {v[o+4]} K loop {v[o+5]} cycles ({Cc // 8} chunks)")
     t_f, t_fd = timed(filt), timed(filt_d)
     filt()
     t_p = timed(wino_pre)
