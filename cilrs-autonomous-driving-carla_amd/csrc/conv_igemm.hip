@@ -40,6 +40,7 @@ namespace {
 
 constexpr int BK = 32;
 constexpr int APITCH = BK + 4;
+constexpr int kSplitKInKernelDefault = 0;      // see launch_conv_igemm
 
 __device__ float g_zero_page[64];   // zero-initialised; target of out-of-image gathers
 
@@ -465,9 +466,12 @@ void conv_igemm_kernel(const ConvArgs a, const int M_, const int Krow, const int
 
     // ---- split-K: every K-slice block parks its partial tile in a slab; the block that draws the
     // last ticket of the tile sums the slabs in slice order (deterministic) and runs the epilogue.
-    // Publish / acquire follow cdna_hip_programming.md "In-launch split-K reduction": plain slab
-    // stores -> every wave drains vmcnt -> barrier -> one lane: agent release fence, drain,
-    // relaxed agent-scope ticket; the last arriver: agent acquire fence, drain, barrier, plain loads.
+    // Hand-off WITHOUT release / acquire fences (cdna guide G16, "every load sc1" form; the same
+    // protocol as csrc/infer_b1.hip): slab stores are write-through (`sc1`: a whole 128-B line per
+    // wave instruction), every storing wave drains them, a workgroup barrier, ONE relaxed
+    // agent-scope ticket add whose returned value tells the last arriver, which then reads every
+    // slab with `sc1` loads.  (Round 1's version fenced -- an agent release per block writes back
+    // the XCD's whole L2, ~20 MB of dirty output here -- and lost to a separate reduce launch.)
     bool inkernel_reduce = false;
     if (a.splitk > 1 && a.tile_counters != nullptr) {
         inkernel_reduce = true;
@@ -481,25 +485,21 @@ void conv_igemm_kernel(const ConvArgs a, const int M_, const int Krow, const int
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = mbase + (r & 3) + 8 * (r >> 2);
-                    if (m < M) slab[(size_t)m * a.y_ld + co] = acc[i][j][r];
+                    if (m < M)
+                        __hip_atomic_store(&slab[(size_t)m * a.y_ld + co], acc[i][j][r],
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         volatile int* flag = reinterpret_cast<volatile int*>(smem);
         if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const int prev = __hip_atomic_fetch_add(&a.tile_counters[logical], 1, __ATOMIC_RELAXED,
                                                     __HIP_MEMORY_SCOPE_AGENT);
             const int last = (prev == a.splitk - 1) ? 1 : 0;
-            if (last) {
-                // leave the counter ready for the next launch; nobody else touches it any more
+            if (last)       // leave the counter ready for the next launch; nobody else touches it
                 __hip_atomic_store(&a.tile_counters[logical], 0, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
             flag[0] = last;
         }
         __syncthreads();
@@ -519,7 +519,9 @@ void conv_igemm_kernel(const ConvArgs a, const int M_, const int Krow, const int
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int m = mbase + (r & 3) + 8 * (r >> 2);
-                        if (m < M) acc[i][j][r] += sl[(size_t)m * a.y_ld + co];
+                        if (m < M)
+                            acc[i][j][r] += __hip_atomic_load(&sl[(size_t)m * a.y_ld + co],
+                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
             }
@@ -994,11 +996,11 @@ int launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
     // in-kernel reduction needs one ticket counter per output tile (zero before the launch; the
     // last arriver re-zeroes it).  Counters live at the head of the scratch unless given.
     const int n_tiles = cdiv(M, kCfg[ch.cfg].bm) * (a.Cout / kCfg[ch.cfg].bn);
-    // Measured (profiles/, r01): the agent-scope release every slice block must execute costs more
-    // than the separate reduce launch it saves (train step +9 %, B=1 inference 2.6x), so the
-    // in-kernel path is opt-in (CILRS_SPLITK_INKERNEL=1); the default is slabs + reduce kernel.
+    // Round 1 measured the FENCED in-kernel combine slower than a separate reduce launch (train
+    // step +9 %); the fence-free form (sc1 slabs + ticket) is A/B'd with CILRS_SPLITK_INKERNEL=0|1
+    // (profiles/r03_splitk_ab.log).
     static const int inkernel_on =
-        getenv("CILRS_SPLITK_INKERNEL") ? atoi(getenv("CILRS_SPLITK_INKERNEL")) : 0;
+        getenv("CILRS_SPLITK_INKERNEL") ? atoi(getenv("CILRS_SPLITK_INKERNEL")) : kSplitKInKernelDefault;
     bool inkernel = false;
     if (!inkernel_on) a.tile_counters = nullptr;
     if (a.splitk > 1 && inkernel_on) {

@@ -620,13 +620,13 @@ def _grad_budget_check(tag, named_oracle_params, gv, g64, coef, cos_floor=1e-5, 
     cos_floor).  Returns 1 - cos.
     realisations: gradients of the same step from OTHER fp32 CPU realisations (thread count,
     memory format).  With them the per-tensor floor is what those realisations show -- the worst
-    of their errors against float64 and of their distances from each other, times 2 -- instead
-    of the constant 5e-3 (round 2's gate flipped on a tensor at 5.57e-3 after a legal change of
+    of their errors against float64 and of their distances from each other: every tensor within
+    4x of it, at most 5 % of the tensors above 2x -- instead of the constant 5e-3 (round 2's gate flipped on a tensor at 5.57e-3 after a legal change of
     summation order; measured here the CPU realisations themselves sit up to ~1e-2 apart)."""
     dot = n1 = n2 = 0.0
     cdot = cn1 = 0.0
     worst_gpu = worst_cpu = 0.0
-    errs = []
+    errs, ratios = [], []
     for n, p in named_oracle_params:
         mine = gv[n].detach().cpu().double() * coef
         ref64 = g64[n] * coef
@@ -641,7 +641,8 @@ def _grad_budget_check(tag, named_oracle_params, gv, g64, coef, cos_floor=1e-5, 
             spread = max(float((alts[i] - alts[j]).norm()) / nrm
                          for i in range(len(alts)) for j in range(i))
             floor = max(max(e_alt), spread)
-            assert e_gpu <= max(4.0 * e_cpu, 2.0 * floor), (tag, n, e_gpu, e_alt, spread)
+            ratios.append((e_gpu / max(floor, 1e-12), n))
+            assert e_gpu <= max(4.0 * e_cpu, 4.0 * floor), (tag, n, e_gpu, e_alt, spread)
         gmax = max(float(ref64.abs().max()), 1e-12)
         m_gpu = float((mine - ref64).abs().max())
         m_cpu = float((p.grad.double() - ref64).abs().max())
@@ -664,6 +665,15 @@ def _grad_budget_check(tag, named_oracle_params, gv, g64, coef, cos_floor=1e-5, 
           f"{med_gpu:.3e}; CPU-fp32 oracle worst {worst_cpu:.3e} median {med_cpu:.3e}; "
           f"1-cos(all grads) = {1 - cos:.3e}")
     assert med_gpu <= max(10.0 * med_cpu, 1e-4)
+    if ratios:
+        # Against the measured floor (worst CPU realisation error / spread of that tensor): a
+        # tensor may sit above it -- which tensors a handful of flipped ReLU decisions land on is
+        # random in every implementation -- but only a few may, and none far (4x, asserted above)
+        ratios.sort(reverse=True)
+        above = sum(1 for r, _ in ratios if r > 2.0)
+        print(f"{tag}: engine error / measured CPU floor per tensor: worst {ratios[0][0]:.2f} "
+              f"({ratios[0][1]}), median {ratios[len(ratios) // 2][0]:.2f}, {above} of {len(ratios)} above 2x")
+        assert above <= max(3, len(ratios) // 20), (tag, ratios[:5])
     cpu_omc = 1.0 - cdot / (cn1 ** 0.5 * n2 ** 0.5)
     assert 1.0 - cos <= max(4.0 * cpu_omc, cos_floor), (tag, 1.0 - cos, cpu_omc)
     return 1.0 - cos
@@ -719,9 +729,21 @@ def test_train_step_b128_vs_oracle(cfg_name):
     pc2, ps2 = alt(imgs.contiguous(memory_format=torch.channels_last), spds, cmds)
     loss2, _ = O.compute_loss(ocfg, pc2, tgts, ps2, spds)
     loss2.backward()
-    alt_g = {n: p.grad for n, p in alt.named_parameters()}       # unclipped; the check scales it
+    reals = [{n: p.grad for n, p in alt.named_parameters()}]     # unclipped; the check scales it
+
+    def another(threads, mkldnn):
+        torch.set_num_threads(threads)
+        o = O.build_oracle(0).train()
+        with torch.backends.mkldnn.flags(enabled=mkldnn):
+            pc3, ps3 = o(imgs, spds, cmds)
+            l3, _ = O.compute_loss(ocfg, pc3, tgts, ps3, spds)
+            l3.backward()
+        torch.set_num_threads(usable_cores())
+        return {n: p.grad for n, p in o.named_parameters()}
+    reals.append(another(max(1, usable_cores() // 2), True))      # other work partition
+    reals.append(another(usable_cores(), False))                  # torch's native convolution path
     omc = _grad_budget_check(f"B=128 cfg {cfg_name}", list(orc.named_parameters()),
-                             _grad_views(eng), g64, coef, realisations=[alt_g])
+                             _grad_views(eng), g64, coef, realisations=reals)
     assert omc <= 1e-5
     # train-mode BatchNorm at B = 128: running statistics of all 36 layers, element-wise
     sd, osd = m.state_dict(), orc.state_dict()
