@@ -303,6 +303,19 @@ int launch_wino_weights(const float* w, float* U, int K, int C, int dgrad, hipSt
 bool wino_supported(int C, int K, int ksize, int stride, int pad);
 int wino_groups(int N, int H, int W);        // column-partial rows a launch writes
 int launch_conv_wino(const WinoArgs& a, hipStream_t s);
+int wino_prepare();                          // one-time kernel attribute (call outside stream capture)
+// Both filter forms of every Winograd convolution of a network in ONE launch (the weights change
+// every optimiser step): block = 8 output x 32 input channels of one layer, staged through LDS so
+// that both images are written in 256-byte / 1-KB contiguous runs.
+struct WinoWeightTable {
+    int n;
+    int K[kMaxConvs], C[kMaxConvs];
+    unsigned w[kMaxConvs];           // OHWI weights in the parameter arena (floats)
+    unsigned u[kMaxConvs];           // forward form  [16][C/8][K][8], floats from `ubase`
+    unsigned ud[kMaxConvs];          // data-gradient form [16][K/8][C][8]
+    int blk_begin[kMaxConvs + 1];    // prefix sums of (K/8) * (C/32)
+};
+int launch_wino_weights_all(const WinoWeightTable& t, const float* params, float* ubase, hipStream_t s);
 
 // ---- persistent single-frame inference kernel (infer_b1.hip) ---------------------------------
 // The whole eval forward of ONE frame (reference control loop, model/autonomous_drive.py:908-920)

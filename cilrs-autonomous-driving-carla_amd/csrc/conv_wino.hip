@@ -16,18 +16,22 @@
 // [xi][C/8][K][8] so a block's slice of a reduction chunk is contiguous.
 //
 // Block = 512 threads (8 waves, one block per CU); tile = 64 output tiles (2x2 pixels each) x 64
-// output channels x all 16 xi; wave w owns xi = 2w, 2w+1 for the whole tile (128 accumulator
-// registers: 2 xi x 2x2 sub-tiles of 32x32); reduction in chunks of 8 input channels:
+// output channels x all 16 xi; wave w owns 16 tiles x 32 channels FOR ALL 16 xi (128 accumulator
+// registers: 16 xi x 2 blocks of v_mfma_f32_16x16x4_f32 with the CHANNELS as the rows), so a lane
+// ends up with the 16 transform-domain values of four consecutive channels of one tile and the
+// inverse transform is register-local (the first version gave each wave 2 xi of the whole tile on
+// 32x32x2 MFMAs and exchanged the accumulators through LDS: 17.5k cycles of epilogue per block
+// against 4.5k here).  Reduction in chunks of 8 input channels:
 //   * gather + transform: four waves (one per SIMD), thread = (tile, channel pair): 16 8-byte
 //     buffer loads (a patch pixel outside the image gets the offset ~0 = out of range = zeros),
 //     32 packed additions, 16 8-byte LDS stores;
 //   * U chunk: 32 KB, contiguous 2 KB per xi;  both are fetched one chunk ahead into registers;
-//   * multiply: per xi two A and two B fragments (ds_read_b128), 16 v_mfma_f32_32x32x2_f32; two
-//     LDS stages, one barrier per chunk;
-//   * epilogue, per 32x32 sub-tile: accumulators -> LDS [xi][tile][channel], inverse transform by
-//     (tile, channel) threads, then the same fused work as the implicit-GEMM kernel: residual /
-//     addend, BatchNorm batch statistics (forward) or BatchNorm-backward reductions (data
-//     gradient) as per-block column partials, 128-byte coalesced stores.
+//   * multiply: per xi one V and two U fragments (8-byte LDS reads, 512 contiguous bytes per
+//     wave, read two xi ahead), four MFMAs; two LDS stages;
+//   * epilogue: inverse transform in registers, then the same fused work as the implicit-GEMM
+//     kernel: residual / addend, BatchNorm batch statistics (forward) or BatchNorm-backward
+//     reductions (data gradient) as per-block column partials, 16-byte stores (64 contiguous
+//     bytes per tile pixel and wave).
 // fp32 Winograd is not bit-identical to the direct sum (other rounding points): outputs differ
 // by a few 1e-6 relative, inside the 1e-4 contract (tests/test_ops_gpu.py).
 #include "common.h"
@@ -38,15 +42,80 @@ namespace {
 constexpr int WT = 64;             // output tiles per block
 constexpr int WK = 64;             // output channels per block
 constexpr int WC = 8;              // input channels per reduction chunk
-constexpr int WP = 8;              // LDS row pitch (floats) of the V / U images: no pad, so that TWO
-                                   // stages fit (2 x 64 KB); a fragment read is 2-way conflicted,
-                                   // which 8 reads per 32 MFMAs do not notice
+constexpr int WP = 8;              // LDS row pitch (floats) of the V / U images: no pad -- TWO stages fit
+                                   // (2 x 64 KB) and a fragment read covers 512 contiguous bytes
 constexpr int WTHREADS = 512;
-// timing experiments (tools/wino_dbg.sh; results meaningless): 1 no global loads, 2 no LDS stores
-// of a chunk, 4 no MFMAs, 8 no epilogue
+typedef unsigned int u32x4w __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// timing experiments (tools/wino_dbg.sh; results meaningless): 1 no global loads, 2 no transform +
+// LDS stores of a chunk, 4 no MFMAs, 8 no LDS fragment reads
 #ifndef CILRS_WINO_DBG
 #define CILRS_WINO_DBG 0
 #endif
+
+// u = G g G^T;  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+__device__ __forceinline__ void wino_filter(const float (&g)[3][3], float (&u)[16]) {
+    float t[4][3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        t[0][b] = g[0][b];
+        t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+        t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+        t[3][b] = g[2][b];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        u[a * 4 + 0] = t[a][0];
+        u[a * 4 + 1] = 0.5f * (t[a][0] + t[a][1] + t[a][2]);
+        u[a * 4 + 2] = 0.5f * (t[a][0] - t[a][1] + t[a][2]);
+        u[a * 4 + 3] = t[a][2];
+    }
+}
+
+// every layer, both forms (WinoWeightTable): thread = (k, c) of an 8 x 32 block of one layer
+__global__ __launch_bounds__(256) void wino_weights_all_kernel(const WinoWeightTable t,
+                                                               const float* __restrict__ params,
+                                                               float* __restrict__ ubase) {
+    __shared__ float sf[16][8][33], sb[16][8][33];
+    int e = 0;
+    while (e + 1 < t.n && (int)blockIdx.x >= t.blk_begin[e + 1]) ++e;      // block-uniform
+    const int K = t.K[e], C = t.C[e];
+    const int b = blockIdx.x - t.blk_begin[e], ncb = C >> 5;
+    const int kb = b / ncb, cb = b - kb * ncb;
+    const int tid = threadIdx.x, kk = tid >> 5, cc = tid & 31;
+    const float* w = params + t.w[e] + ((size_t)(kb * 8 + kk) * 9) * C + cb * 32 + cc;
+    float g[3][3], gf[3][3], uf[16], ub[16];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) g[i][j] = w[(size_t)(i * 3 + j) * C];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) gf[i][j] = g[2 - i][2 - j];
+    wino_filter(g, uf);
+    wino_filter(gf, ub);
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) { sf[xi][kk][cc] = uf[xi]; sb[xi][kk][cc] = ub[xi]; }
+    __syncthreads();
+    float* U = ubase + t.u[e];
+    float* Ud = ubase + t.ud[e];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int f = it * 256 + tid;
+        {   // forward form [xi][C/8][K][8]: float4 index = [xi 16][c8 4][k 8][2]
+            const int q = f & 1, k = (f >> 1) & 7, c8 = (f >> 4) & 3, xi = f >> 6;
+            const float* src = &sf[xi][k][c8 * 8 + q * 4];
+            *reinterpret_cast<f32x4*>(U + (((size_t)xi * (C >> 3) + cb * 4 + c8) * K + kb * 8 + k) * 8 + q * 4) =
+                f32x4{src[0], src[1], src[2], src[3]};
+        }
+        {   // data-gradient form [xi][K/8][C][8]: float4 index = [xi 16][c 32][2]
+            const int q = f & 1, c = (f >> 1) & 31, xi = f >> 6;
+            *reinterpret_cast<f32x4*>(Ud + (((size_t)xi * (K >> 3) + kb) * C + cb * 32 + c) * 8 + q * 4) =
+                f32x4{sb[xi][q * 4 + 0][c], sb[xi][q * 4 + 1][c], sb[xi][q * 4 + 2][c], sb[xi][q * 4 + 3][c]};
+        }
+    }
+}
 
 // U[xi][c/8][k][c%8] = (G g G^T)[xi] of g = w[k][.][.][c]  (OHWI weights)
 // dgrad = 1: the data-gradient filter instead: g' = 180-degree flip of w[c_out..] with the channel
@@ -97,7 +166,8 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
     float* Vs = smem;                          // [2 stages]: [16][WT][WP] | [16][WK][WP]
     float* Us = smem + 16 * WT * WP;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, lh = lane >> 5;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int tg = wave & 3, kg = wave >> 2;   // this wave's 16 tiles / 32 output channels
     const int TH = (a.H + 1) >> 1, TW = (a.W + 1) >> 1;
     const int tiles_img = TH * TW, total_tiles = a.N * tiles_img;
     const int nkt = a.K / WK;
@@ -130,9 +200,7 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
     // U chunk: thread handles 4 float4: xi = 4 pass + (tid >> 7), float4 index tid & 127 of the
     // xi's contiguous [64 k][8 c] slice
     const int u_idx = tid & 127, u_xi0 = tid >> 7;
-    const unsigned u_lds = (unsigned)((u_idx >> 1) * WP + (u_idx & 1) * 4);
 
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
     f32x2 d[16];
     f32x4 ur[4];
     auto load_chunk = [&](const int ch) {
@@ -149,94 +217,105 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
             for (int p = 0; p < 16; ++p)
                 d[p] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsX, (int)voff[p], soff, 0));
         }
+        const int usoff = (ch * a.K + k0) * 32;           // bytes: [ch][k0] of an xi plane
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int xi = q * 4 + u_xi0;
-            const unsigned off = (unsigned)((((size_t)xi * nchunks + ch) * a.K + k0) * 8 + u_idx * 4) * 4u;
-            ur[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsU, (int)off, 0, 0));
+            const unsigned off = (unsigned)(xi * nchunks * a.K * 8 + u_idx * 4) * 4u;
+            ur[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsU, (int)off, usoff, 0));
         }
+    };
+    // V = B^T d B in two steps, in place;  B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]
+    auto transform_col = [&](const int j) {         // r = B^T d, column j of the patch
+        const f32x2 r0 = d[0 * 4 + j] - d[2 * 4 + j];
+        const f32x2 r1 = d[1 * 4 + j] + d[2 * 4 + j];
+        const f32x2 r2 = d[2 * 4 + j] - d[1 * 4 + j];
+        const f32x2 r3 = d[1 * 4 + j] - d[3 * 4 + j];
+        d[0 * 4 + j] = r0; d[1 * 4 + j] = r1; d[2 * 4 + j] = r2; d[3 * 4 + j] = r3;
+    };
+    auto transform_row = [&](const int i, const int stage) {     // V row i = r B, stored
+        const f32x2 v0 = d[i * 4 + 0] - d[i * 4 + 2];
+        const f32x2 v1 = d[i * 4 + 1] + d[i * 4 + 2];
+        const f32x2 v2 = d[i * 4 + 2] - d[i * 4 + 1];
+        const f32x2 v3 = d[i * 4 + 1] - d[i * 4 + 3];
+        float* dst = Vs + stage * STAGE + (i * 4) * (WT * WP) + g_tile * WP + g_p * 2;
+        *reinterpret_cast<f32x2*>(dst + 0 * WT * WP) = v0;
+        *reinterpret_cast<f32x2*>(dst + 1 * WT * WP) = v1;
+        *reinterpret_cast<f32x2*>(dst + 2 * WT * WP) = v2;
+        *reinterpret_cast<f32x2*>(dst + 3 * WT * WP) = v3;
+    };
+    auto store_u = [&](const int stage) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<f32x4*>(Us + stage * STAGE + (q * 4 + u_xi0) * (WK * WP) + u_idx * 4) = ur[q];
     };
     auto store_chunk = [&](const int stage) {
         if (CILRS_WINO_DBG & 2) {
             asm volatile("" ::"v"(d[0]), "v"(d[15]), "v"(ur[0]), "v"(ur[3]));
             return;
         }
-        // V = B^T d B;  B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]
         if (gatherer) {
-            f32x2 r[16];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                r[0 * 4 + j] = d[0 * 4 + j] - d[2 * 4 + j];
-                r[1 * 4 + j] = d[1 * 4 + j] + d[2 * 4 + j];
-                r[2 * 4 + j] = d[2 * 4 + j] - d[1 * 4 + j];
-                r[3 * 4 + j] = d[1 * 4 + j] - d[3 * 4 + j];
-            }
+            for (int j = 0; j < 4; ++j) transform_col(j);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const f32x2 v0 = r[i * 4 + 0] - r[i * 4 + 2];
-                const f32x2 v1 = r[i * 4 + 1] + r[i * 4 + 2];
-                const f32x2 v2 = r[i * 4 + 2] - r[i * 4 + 1];
-                const f32x2 v3 = r[i * 4 + 1] - r[i * 4 + 3];
-                float* dst = Vs + stage * STAGE + (i * 4) * (WT * WP) + g_tile * WP + g_p * 2;
-                *reinterpret_cast<f32x2*>(dst + 0 * WT * WP) = v0;
-                *reinterpret_cast<f32x2*>(dst + 1 * WT * WP) = v1;
-                *reinterpret_cast<f32x2*>(dst + 2 * WT * WP) = v2;
-                *reinterpret_cast<f32x2*>(dst + 3 * WT * WP) = v3;
-            }
+            for (int i = 0; i < 4; ++i) transform_row(i, stage);
         }
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<f32x4*>(Us + stage * STAGE + (q * 4 + u_xi0) * (WK * WP) + u_lds) = ur[q];
+        store_u(stage);
     };
 
-    f32x16 acc[2][2][2];             // [xi of this wave][row sub-tile][channel sub-tile]
+    // M^T[xi] (channels x tiles) of this wave: rows = 2 x 16 output channels, columns = 16 tiles.
+    // v_mfma_f32_16x16x4_f32: lane l holds rows 4 (l >> 4) .. + 3 of column l & 15, i.e. FOUR
+    // CONSECUTIVE CHANNELS OF ONE TILE for all 16 xi: the inverse transform is register-local.
+    f32x4 acc[16][2];
 #pragma unroll
-    for (int x = 0; x < 2; ++x)
+    for (int x = 0; x < 16; ++x)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[x][i][j][e] = 0.f;
+        for (int m = 0; m < 2; ++m) acc[x][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // Two LDS stages: while a wave multiplies chunk ch out of stage ch & 1, the chunk after it is
-    // already on its way from global memory (registers) and is transformed and stored into the
-    // other stage right behind the multiplies -- ONE barrier per chunk, and the waves of a SIMD
-    // drift apart so that one's LDS stores run under the other's MFMAs.
     const long long tm_start = (a.stamps != nullptr && blockIdx.x == 0) ? __builtin_amdgcn_s_memtime() : 0;
     load_chunk(0);
     store_chunk(0);
     if (nchunks > 1) load_chunk(1);
     __syncthreads();
-    // The two waves of a SIMD run the same program; left alone they multiply together (half the
-    // matrix pipe each) and then transform / store together (pipe idle).  Waves 4-7 therefore do
-    // the two halves of an iteration in the OTHER order: one wave's MFMAs run under its partner's
-    // transform + LDS stores.  (Stage ch & 1 is complete at the top of iteration ch; the stores
-    // of chunk ch + 1 go to the other stage, which nobody has read since iteration ch - 1.)
-    const bool late = wave >= 4;
+    // operand fragments: the k index of a lane is lq, it covers channels 2 lq, 2 lq + 1 of the
+    // chunk (one 8-byte read feeds the two k-steps); 64 lanes read 512 contiguous bytes
+    const int frag_v = (tg * 16 + l15) * WP + lq * 2;
+    const int frag_u = (kg * 32 + l15) * WP + lq * 2;
+    // fragments of xi + D are read while the MFMAs of xi run (an LDS read that an MFMA waits on
+    // exposes its whole latency: with eight waves reading it is several hundred cycles)
     auto multiply = [&](const int ch) {
-        const float* Vc = Vs + (ch & 1) * STAGE;
-        const float* Uc = Us + (ch & 1) * STAGE;
+        const float* Vc = Vs + (ch & 1) * STAGE + frag_v;
+        const float* Uc = Us + (ch & 1) * STAGE + frag_u;
+        constexpr int D = 2;
+        f32x2 bv[D + 1], a0[D + 1], a1[D + 1];
 #pragma unroll
-        for (int x = 0; x < 2; ++x) {
-            const int xi = 2 * wave + x;
-            f32x4 af[2], bf[2];
+        for (int x = 0; x < D; ++x) {
+            bv[x] = *reinterpret_cast<const f32x2*>(Vc + x * (WT * WP));
+            a0[x] = *reinterpret_cast<const f32x2*>(Uc + x * (WK * WP));
+            a1[x] = *reinterpret_cast<const f32x2*>(Uc + x * (WK * WP) + 16 * WP);
+        }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-                af[i] = *reinterpret_cast<const f32x4*>(Vc + xi * (WT * WP) + (i * 32 + l31) * WP + lh * 4);
+        for (int xi = 0; xi < 16; ++xi) {
+            const int cur = xi % (D + 1), nxt = (xi + D) % (D + 1);
+            if (CILRS_WINO_DBG & 8) {
+                bv[nxt] = f32x2{(float)xi, 1.f}; a0[nxt] = f32x2{(float)lane, 2.f}; a1[nxt] = f32x2{3.f, (float)xi};
+            } else if (xi + D < 16) {
+                bv[nxt] = *reinterpret_cast<const f32x2*>(Vc + (xi + D) * (WT * WP));
+                a0[nxt] = *reinterpret_cast<const f32x2*>(Uc + (xi + D) * (WK * WP));
+                a1[nxt] = *reinterpret_cast<const f32x2*>(Uc + (xi + D) * (WK * WP) + 16 * WP);
+            }
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-                bf[j] = *reinterpret_cast<const f32x4*>(Uc + xi * (WK * WP) + (j * 32 + l31) * WP + lh * 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        if (!(CILRS_WINO_DBG & 4))
-                        acc[x][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e],
-                                                                            acc[x][i][j], 0, 0, 0);
-                        else acc[x][i][j][e] += af[i][e] * bf[j][e];
+            for (int s = 0; s < 2; ++s) {
+                if (!(CILRS_WINO_DBG & 4)) {
+                    acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[cur][s], bv[cur][s], acc[xi][0], 0, 0, 0);
+                    acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[cur][s], bv[cur][s], acc[xi][1], 0, 0, 0);
+                } else {
+                    acc[xi][0][s] += a0[cur][s] * bv[cur][s];
+                    acc[xi][1][s] += a1[cur][s] * bv[cur][s];
+                }
+            }
+            if (xi + D < 16) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);    // 3 LDS reads,
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                      // then 4 MFMAs
         }
     };
     auto refill = [&](const int ch) {                   // chunk ch + 1 into the other stage
@@ -245,132 +324,150 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
             if (ch + 2 < nchunks) load_chunk(ch + 2);
         }
     };
+    // Two phases per chunk, a barrier after each: waves 0-3 multiply while waves 4-7 store their
+    // part of the next chunk, then the roles swap (one wave's MFMAs over its SIMD partner's
+    // transform + LDS stores).  Measured alternatives, cycles per chunk on layer1 (block 0):
+    // both waves multiply, then both refill (fair-shared pipe, transform with the pipe idle) 6.9k;
+    // the same with s_setprio for the gathering wave 6.9k (MFMA arbitration ignores it); the
+    // transform cut into pieces BETWEEN the MFMA groups of the gathering wave 6.9k; this form 6.3k;
+    // MFMAs alone (no loads, no LDS traffic) 5.0k, of which 4.1k is the pipe's issue rate.
+    const bool late = wave >= 4;
     // diagnostics (WinoArgs::stamps, tools/wino_bench.py): where block 0's waves 0 and 4 spend a
-    // launch, in shader cycles: [prologue, multiply, refill, barrier wait, epilogue]
-    long long tm_mul = 0, tm_ref = 0, tm_bar = 0;
+    // launch, in shader cycles: [prologue, first phase incl. its barrier, second phase, end
+    // barrier, epilogue, K loop]
+    long long tm_a = 0, tm_b = 0, tm_bar = 0;
     const bool stamp = a.stamps != nullptr && blockIdx.x == 0 && (tid == 0 || tid == 256);
     const long long tm0 = tm_start;
     long long tm_loop0 = 0;
     if (stamp) tm_loop0 = __builtin_amdgcn_s_memtime();
     for (int ch = 0; ch < nchunks; ++ch) {
-        long long ta = 0, tb = 0, tc = 0, td = 0;
+        long long ta = 0, tb = 0, tc = 0;
         if (stamp) ta = __builtin_amdgcn_s_memtime();
         if (late) {
             refill(ch);
             __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
             if (stamp) tb = __builtin_amdgcn_s_memtime();
             multiply(ch);
         } else {
             multiply(ch);
             __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
             if (stamp) tb = __builtin_amdgcn_s_memtime();
             refill(ch);
         }
         if (stamp) tc = __builtin_amdgcn_s_memtime();
         __syncthreads();
         if (stamp) {
-            td = __builtin_amdgcn_s_memtime();
-            if (late) { tm_ref += tb - ta; tm_mul += tc - tb; } else { tm_mul += tb - ta; tm_ref += tc - tb; }
-            tm_bar += td - tc;
+            tm_a += tb - ta;
+            tm_b += tc - tb;
+            tm_bar += __builtin_amdgcn_s_memtime() - tc;
         }
     }
     const long long tm_loop1 = stamp ? __builtin_amdgcn_s_memtime() : 0;
 
-    if (CILRS_WINO_DBG & 8) {
-        if (acc[0][0][0][0] == 123.f) a.y[tid] = acc[1][1][1][3];
-        return;
+    // ---- epilogue: this lane's tile (one per lane) and its 2 x 4 consecutive channels ----
+    const int t = blk_m * WT + tg * 16 + l15;
+    const bool tv = t < total_tiles;
+    const int n = tv ? t / tiles_img : 0, rem = t - n * tiles_img;
+    const int ty = rem / TW, tx = rem - ty * TW;
+    const int co = k0 + kg * 32 + lq * 4;                   // + 16 mb
+    const size_t ybytes = (size_t)a.N * a.H * a.W * a.K * 4;
+    const int yrec = (int)(unsigned)ybytes;
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, yrec, 0x00020000);
+    unsigned yoff[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int oy = 2 * ty + (q >> 1), ox = 2 * tx + (q & 1);
+        const bool ok = tv && oy < a.H && ox < a.W;
+        yoff[q] = ok ? (unsigned)((((n * a.H + oy) * a.W + ox) * a.K + co) * 4) : 0xFFFFFFFFu;
     }
-    float* Ms = smem;                           // [16][32][32] = 64 KB (the K loop ended on a barrier)
-    float cs1[2] = {0.f, 0.f}, cs2[2] = {0.f, 0.f};     // column partials of this thread's channel
-    const int e_col = tid & 31;                 // channel within the sub-tile
-    const int e_t0 = tid >> 5;                  // tiles e_t0 and e_t0 + 16 of the sub-tile
     const bool stats_fwd = a.bn_partial != nullptr, stats_bwd = a.bwd_partial != nullptr;
+    f32x4 ad[2][4];
+    if (a.addend) {
+        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.addend, 0, yrec, 0x00020000);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+        for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+            for (int q = 0; q < 4; ++q)
+                ad[mb][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)yoff[q], mb * 64, 0));
+    }
+    f32x4 cs1[2], cs2[2];
 #pragma unroll
-            for (int x = 0; x < 2; ++x) {
-                float* mp = Ms + (2 * wave + x) * 1024 + l31;
+    for (int mb = 0; mb < 2; ++mb) {
+        // Y = A^T M A;  A^T = [[1,1,1,0],[0,1,-1,-1]]
+        f32x4 s0[4], s1[4];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    mp[row * 32] = acc[x][i][j][r];
+        for (int q = 0; q < 4; ++q) {
+            s0[q] = acc[0 * 4 + q][mb] + acc[1 * 4 + q][mb] + acc[2 * 4 + q][mb];
+            s1[q] = acc[1 * 4 + q][mb] - acc[2 * 4 + q][mb] - acc[3 * 4 + q][mb];
+        }
+        f32x4 y[4];
+        y[0] = s0[0] + s0[1] + s0[2];
+        y[1] = s0[1] - s0[2] - s0[3];
+        y[2] = s1[0] + s1[1] + s1[2];
+        y[3] = s1[1] - s1[2] - s1[3];
+        if (a.addend) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) y[q] += ad[mb][q];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4w, y[q]), rsY, (int)yoff[q], mb * 64, 0);
+        cs1[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        cs2[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (stats_fwd) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = yoff[q] != 0xFFFFFFFFu ? y[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+                cs1[mb] += v;
+                cs2[mb] += v * v;
+            }
+        } else if (stats_bwd) {
+            const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc((void*)a.bwd_z, 0, yrec, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.bwd_y, 0, yrec, 0x00020000);
+            const f32x4 bmean = *reinterpret_cast<const f32x4*>(a.bwd_stats + co + mb * 16);
+            const f32x4 brstd = *reinterpret_cast<const f32x4*>(a.bwd_stats + a.K + co + mb * 16);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 zz = f32x4{1.f, 1.f, 1.f, 1.f};
+                if (a.bwd_relu)
+                    zz = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsZ, (int)yoff[q], mb * 64, 0));
+                const f32x4 yy = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)yoff[q], mb * 64, 0));
+                const bool ok = yoff[q] != 0xFFFFFFFFu;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float g = (ok && zz[e] > 0.f) ? y[q][e] : 0.f;
+                    cs1[mb][e] += g;
+                    cs2[mb][e] = fmaf(g, (yy[e] - bmean[e]) * brstd[e], cs2[mb][e]);
                 }
             }
-            __syncthreads();
-            const int co = k0 + j * 32 + e_col;
-            float bmean = 0.f, brstd = 0.f;
-            if (stats_bwd) { bmean = a.bwd_stats[co]; brstd = a.bwd_stats[a.K + co]; }
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const int tl = e_t0 + 16 * half;              // tile within the sub-tile
-                float m[16];
-#pragma unroll
-                for (int xi = 0; xi < 16; ++xi) m[xi] = Ms[xi * 1024 + tl * 32 + e_col];
-                // Y = A^T M A;  A^T = [[1,1,1,0],[0,1,-1,-1]]
-                float s0[4], s1[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    s0[q] = m[0 * 4 + q] + m[1 * 4 + q] + m[2 * 4 + q];
-                    s1[q] = m[1 * 4 + q] - m[2 * 4 + q] - m[3 * 4 + q];
-                }
-                float y[4];
-                y[0] = s0[0] + s0[1] + s0[2];
-                y[1] = s0[1] - s0[2] - s0[3];
-                y[2] = s1[0] + s1[1] + s1[2];
-                y[3] = s1[1] - s1[2] - s1[3];
-                const int t = blk_m * WT + i * 32 + tl;
-                if (t < total_tiles) {
-                    const int n = t / tiles_img, rem = t - n * tiles_img;
-                    const int ty = rem / TW, tx = rem - ty * TW;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int oy = 2 * ty + (q >> 1), ox = 2 * tx + (q & 1);
-                        if (oy < a.H && ox < a.W) {
-                            const size_t o = ((size_t)(n * a.H + oy) * a.W + ox) * a.K + co;
-                            float v = y[q];
-                            if (a.addend) v += a.addend[o];
-                            a.y[o] = v;
-                            if (stats_fwd) {
-                                cs1[j] += v;
-                                cs2[j] = fmaf(v, v, cs2[j]);
-                            } else if (stats_bwd) {
-                                const float zz = a.bwd_relu ? a.bwd_z[o] : 1.f;
-                                const float g = zz > 0.f ? v : 0.f;
-                                cs1[j] += g;
-                                cs2[j] = fmaf(g, (a.bwd_y[o] - bmean) * brstd, cs2[j]);
-                            }
-                        }
-                    }
-                }
-            }
-            __syncthreads();
         }
     }
     if (stamp) {
         long long* o = a.stamps + (tid == 0 ? 0 : 8);
-        o[0] = tm_loop0 - tm0; o[1] = tm_mul; o[2] = tm_ref; o[3] = tm_bar;
+        o[0] = tm_loop0 - tm0; o[1] = tm_a; o[2] = tm_b; o[3] = tm_bar;
         o[4] = __builtin_amdgcn_s_memtime() - tm_loop1; o[5] = tm_loop1 - tm_loop0;
     }
-    // column partials of this block: [2][K][groups] like the implicit-GEMM kernel's (channel-major),
-    // threads with equal e_col (16 of them) summed in fixed order
+    // column partials of this block: [2][K][groups] like the implicit-GEMM kernel's (channel-major);
+    // the 64 tiles of a channel are summed in fixed order
     if (stats_fwd || stats_bwd) {
-        float* red = smem;                      // [2][2 j][16 t0][32 col]
+        float* red = smem;                      // [2 which][64 tiles][64 channels] (the K loop ended on a barrier)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            red[((0 * 2 + j) * 16 + e_t0) * 32 + e_col] = cs1[j];
-            red[((1 * 2 + j) * 16 + e_t0) * 32 + e_col] = cs2[j];
+        for (int mb = 0; mb < 2; ++mb) {
+            const int c = kg * 32 + mb * 16 + lq * 4;
+            *reinterpret_cast<f32x4*>(red + (0 * 64 + tg * 16 + l15) * 64 + c) = cs1[mb];
+            *reinterpret_cast<f32x4*>(red + (1 * 64 + tg * 16 + l15) * 64 + c) = cs2[mb];
         }
         __syncthreads();
-        if (tid < 128) {                        // (which, j, col)
-            const int which = tid >> 6, j = (tid >> 5) & 1, col = tid & 31;
+        if (tid < 128) {                        // (which, channel)
+            const int which = tid >> 6, col = tid & 63;
             float s = 0.f;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) s += red[((which * 2 + j) * 16 + q) * 32 + col];
+#pragma unroll 8
+            for (int q = 0; q < 64; ++q) s += red[(which * 64 + q) * 64 + col];
             float* dst = stats_fwd ? a.bn_partial : a.bwd_partial;
             const int groups = gridDim.x / nkt;
-            dst[(size_t)(which * a.K + k0 + j * 32 + col) * groups + blk_m] = s;
+            dst[(size_t)(which * a.K + k0 + col) * groups + blk_m] = s;
         }
     }
 }
@@ -386,11 +483,34 @@ int launch_wino_weights(const float* w, float* U, int K, int C, int dgrad, hipSt
     return 0;
 }
 
+int launch_wino_weights_all(const WinoWeightTable& t, const float* params, float* ubase, hipStream_t s) {
+    if (t.n <= 0) return 0;
+    for (int e = 0; e < t.n; ++e)
+        CILRS_CHECK(t.K[e] % 8 == 0 && t.C[e] % 32 == 0, "wino_weights_all: K %% 8, C %% 32");
+    wino_weights_all_kernel<<<t.blk_begin[t.n], 256, 0, s>>>(t, params, ubase);
+    CILRS_LAUNCH_CHECK();
+    return 0;
+}
+
 bool wino_supported(int C, int K, int ksize, int stride, int pad) {
     return ksize == 3 && stride == 1 && pad == 1 && C % WC == 0 && K % WK == 0;
 }
 
 int wino_groups(int N, int H, int W) { return cdiv(N * ((H + 1) / 2) * ((W + 1) / 2), WT); }
+
+constexpr size_t kWinoLds = (size_t)2 * (16 * WT * WP + 16 * WK * WP) * sizeof(float);     // 128 KB
+
+// (a plan calls this when it is built: the attribute must not be set for the first time inside a
+//  stream capture)
+int wino_prepare() {
+    static bool attr_set = false;
+    if (!attr_set) {
+        CILRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoLds));
+        attr_set = true;
+    }
+    return 0;
+}
 
 int launch_conv_wino(const WinoArgs& a, hipStream_t s) {
     CILRS_CHECK(a.x && a.U && a.y, "conv_wino: NULL tensor");
@@ -399,15 +519,9 @@ int launch_conv_wino(const WinoArgs& a, hipStream_t s) {
                     (size_t)16 * a.C * a.K * 4 < (1ull << 32),
                 "conv_wino: tensor too large for 32-bit offsets");
     CILRS_CHECK(!(a.bn_partial && a.bwd_partial), "conv_wino: one kind of column partials per launch");
-    constexpr size_t lds = (size_t)2 * (16 * WT * WP + 16 * WK * WP) * sizeof(float);     // 128 KB
-    static bool attr_set = false;
-    if (!attr_set) {
-        CILRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    if (wino_prepare()) return 1;
     const int groups = wino_groups(a.N, a.H, a.W);
-    conv_wino_kernel<<<groups * (a.K / WK), WTHREADS, lds, s>>>(a);
+    conv_wino_kernel<<<groups * (a.K / WK), WTHREADS, kWinoLds, s>>>(a);
     CILRS_LAUNCH_CHECK();
     return 0;
 }

@@ -308,6 +308,14 @@ struct cilrs_net {
     size_t w16_all = 0, wT16 = 0, pool16 = 0, slabs16 = 0, slabs16_floats = 0;
     size_t z16[kMaxConvs] = {}, wT16_off[kMaxConvs] = {}, G16[kNumG] = {};
     TransposeF16Table tr_table;
+    // Winograd F(2x2, 3x3) (conv_wino.hip) for the stride-1 3x3 convolutions of fp32 train plans
+    // where it beats the implicit GEMM (layers of up to 256 channels with enough blocks to fill
+    // the chip; CILRS_WINO=0 turns it off): forward + data gradient.  Both transformed-filter
+    // images of every such layer live in the workspace and are rebuilt by ONE launch at the top
+    // of each training forward (the weights change every step).
+    bool wino_on[kMaxConvs] = {};
+    size_t wino_base = 0;
+    WinoWeightTable wino_table;
     // persistent single-frame kernel (infer_b1.hip): stage table + barrier counters in the
     // workspace (offsets in floats; 0 = this plan has none), uploaded once per workspace
     size_t b1_table = 0, b1_sync = 0, b1_stamps = 0, b1_slabs = 0, b1_slab_floats = 0, b1_cmd = 0;
@@ -416,6 +424,23 @@ int conv_fwd(cilrs_net* net, const ConvT& c, const ConvG& g, const float* x, int
              const float* w, float* y, float* ws, hipStream_t s, int* bn_nblk = nullptr,
              const float* fold_stats = nullptr, int relu = 0, const float* addend = nullptr,
              int relu_post = 0) {
+    const int ci = (int)(&g - &net->cg[0]);
+    if (bn_nblk && !fold_stats && net->wino_on[ci]) {      // training forward on the Winograd kernel
+        WinoArgs wa;
+        memset(&wa, 0, sizeof(wa));
+        int e = 0;
+        while (net->wino_table.w[e] != (unsigned)c.w) ++e;
+        wa.x = x; wa.U = ws + net->wino_base + net->wino_table.u[e]; wa.y = y;
+        wa.N = net->B; wa.H = g.H; wa.W = g.W; wa.C = c.cin; wa.K = c.cout;
+        wa.bn_partial = ws + net->bn_partial;
+        *bn_nblk = wino_groups(net->B, g.H, g.W);
+        const double flops = 2.0 * g.M * c.cout * c.k * c.k * c.cin;      // DIRECT-convolution flops
+        const double bytes = 4.0 * ((double)net->B * g.H * g.W * c.cin + (double)g.M * c.cout +
+                                    16.0 * c.cout * c.cin);
+        RUN(net, std::string("conv_fwd.") + kGroupName[c.group], flops, bytes, s,
+            launch_conv_wino(wa, s));
+        return 0;
+    }
     ConvArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x; a.w = w; a.y = y;
@@ -445,6 +470,27 @@ int conv_fwd(cilrs_net* net, const ConvT& c, const ConvG& g, const float* x, int
 int conv_dgrad(cilrs_net* net, const ConvT& c, const ConvG& g, const float* dy, const float* w,
                float* dx, const float* addend, float* ws, hipStream_t s,
                const ConvG* bn_of = nullptr, int bn_relu = 1, int* bwd_nblk = nullptr) {
+    const int ci = (int)(&g - &net->cg[0]);
+    if (net->wino_on[ci]) {        // the same convolution with the flipped, transposed filter
+        WinoArgs wa;
+        memset(&wa, 0, sizeof(wa));
+        int e = 0;
+        while (net->wino_table.w[e] != (unsigned)c.w) ++e;
+        wa.x = dy; wa.U = ws + net->wino_base + net->wino_table.ud[e]; wa.y = dx; wa.addend = addend;
+        wa.N = net->B; wa.H = g.H; wa.W = g.W; wa.C = c.cout; wa.K = c.cin;
+        if (bwd_nblk) *bwd_nblk = 0;
+        if (bn_of && bwd_nblk) {
+            wa.bwd_z = ws + bn_of->z; wa.bwd_y = ws + bn_of->y; wa.bwd_stats = ws + bn_of->stats;
+            wa.bwd_relu = bn_relu; wa.bwd_partial = ws + net->bn_partial;
+            *bwd_nblk = wino_groups(net->B, g.H, g.W);
+        }
+        const double flops = 2.0 * g.M * c.cout * c.k * c.k * c.cin;
+        const double bytes = 4.0 * ((double)net->B * g.H * g.W * c.cin + (double)g.M * c.cout +
+                                    16.0 * c.cout * c.cin);
+        RUN(net, std::string("conv_dgrad.") + kGroupName[c.group], flops, bytes, s,
+            launch_conv_wino(wa, s));
+        return 0;
+    }
     DgradArgs a;
     memset(&a, 0, sizeof(a));
     a.dy = dy; a.w = w; a.dx = dx; a.addend = addend;
@@ -860,6 +906,38 @@ int cilrs_net_create_ex(int variant, int batch, int height, int width, unsigned 
         n->slabs16_floats = sl;
         n->slabs16 = bump.take(sl > 0 ? sl : 4);
     }
+    n->wino_table.n = 0;
+    n->wino_table.blk_begin[0] = 0;
+    {
+        static const int wino_env = getenv("CILRS_WINO") ? atoi(getenv("CILRS_WINO")) : 1;
+        if (trainable && !(flags & 1u) && wino_env) {
+            size_t floats = 0;
+            for (size_t ci = 1; ci < A.convs.size(); ++ci) {
+                const ConvT& c = A.convs[ci];
+                const ConvG& g = n->cg[ci];
+                if (!wino_supported(c.cin, c.cout, c.k, c.stride, c.pad) ||
+                    !wino_supported(c.cout, c.cin, c.k, c.stride, c.pad) || c.cin % 32 != 0 ||
+                    c.cin > 256 || c.cout > 256)
+                    continue;
+                // one 64-tile x 64-channel block per CU: below ~half a chip of blocks the
+                // implicit GEMM (split-K, smaller tiles) wins (tools/wino_bench.py)
+                const int blocks = wino_groups(B, g.H, g.W) * (std::min(c.cin, c.cout) / 64);
+                if (wino_env == 1 && blocks < 128) continue;
+                WinoWeightTable& t = n->wino_table;
+                const int e = t.n++;
+                t.K[e] = c.cout; t.C[e] = c.cin; t.w[e] = (unsigned)c.w;
+                t.u[e] = (unsigned)floats; floats += wino_weight_floats(c.cout, c.cin);
+                t.ud[e] = (unsigned)floats; floats += wino_weight_floats(c.cout, c.cin);
+                t.blk_begin[e + 1] = t.blk_begin[e] + (c.cout / 8) * (c.cin / 32);
+                n->wino_on[ci] = true;
+            }
+            CILRS_CHECK(floats < (1ull << 32), "Winograd filter images exceed 32-bit offsets");
+            if (n->wino_table.n) {
+                n->wino_base = bump.take(floats);
+                if (wino_prepare()) return 1;
+            }
+        }
+    }
     if (batch == 1 && variant == 0) {
         n->b1_table = bump.take(kB1MaxStages * sizeof(B1Stage) / sizeof(float));
         n->b1_sync = bump.take(kB1SyncInts);
@@ -995,6 +1073,9 @@ static int forward_from_x4(cilrs_net* net, const cilrs_buffers* bufs, const floa
             launch_bn_relu_maxpool_fwd(ws + net->cg[0].y, ws + net->cg[0].stats, ws + net->pool,
                                        argmax, B, net->H0, net->W0, 64, s,
                                        bf16t ? (void*)h16(ws, net->pool16) : nullptr));
+        if (net->wino_table.n)       // this step's transformed filters (forward + data-gradient forms)
+            RUN(net, "transform", 0.0, 4.0 * 4.6 * (double)net->wino_table.blk_begin[net->wino_table.n] * 256, s,
+                launch_wino_weights_all(net->wino_table, P, ws + net->wino_base, s));
         if (bf16t) {
             // this step's 16-bit weights: the whole arena (same offsets as fp32) and the
             // transposed, tap-flipped copies the data gradients read

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Side builds of the library with pieces of the Winograd kernel removed (timing experiments;
 # results are numerically meaningless): libcilrs_hip_wdbg<mask>.so next to the real one.
-# mask bits: 1 no global loads, 2 no LDS stores of a chunk, 4 no MFMAs, 8 no epilogue.
+# mask bits: 1 no global loads, 2 no transform + LDS stores of a chunk, 4 no MFMAs, 8 no LDS fragment reads.
 set -e
 cd "$(dirname "$0")/../cilrs-autonomous-driving-carla_amd/csrc"
 make -s
