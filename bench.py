@@ -370,7 +370,10 @@ def main():
                      ms=fam.get("conv_fwd", {}).get("ms", 0.0) + fam.get("conv_dgrad", {}).get("ms", 0.0),
                      flops=fam.get("conv_fwd", {}).get("flops", 0.0) + fam.get("conv_dgrad", {}).get("flops", 0.0))
         wg = fam.get("conv_wgrad", dict(calls=0, ms=0.0, flops=0.0))
-        dom_name, dom = ("conv_igemm_kernel (fwd+dgrad)", igemm) if igemm["ms"] >= wg["ms"] \
+        nwino = pl.wino_convs()
+        fam_name = "conv fwd+dgrad family: conv_igemm_kernel" + (
+            f" + conv_wino_kernel ({2 * nwino} of the launches)" if nwino else "")
+        dom_name, dom = (fam_name, igemm) if igemm["ms"] >= wg["ms"] \
             else ("conv_wgrad_kernel (+reduce)", wg)
         ach = dom["flops"] / max(dom["ms"], 1e-9) / 1e9          # TFLOP/s
         out["roofline"] = {
@@ -381,6 +384,10 @@ def main():
             "avg_launch_us": round(dom["ms"] / max(dom["calls"], 1) * 1e3, 2),
             "flops_per_launch": round(dom["flops"] / max(dom["calls"], 1), 1),
             "share_of_step": round(dom["ms"] / max(total_ms, 1e-9), 4),
+            # ALGORITHMIC flops = the direct convolution's 2*M*Cout*K*K*Cin for every launch; a
+            # Winograd F(2x2,3x3) launch issues 2.25x fewer multiplies for them
+            "flops_basis": "direct convolution",
+            "winograd_convs": nwino,
         }
         # HBM traffic per launch of that kernel family is NOT measured in this run: it is the
         # committed summary of separate rocprofv3 PMC passes over this same command (FETCH_SIZE

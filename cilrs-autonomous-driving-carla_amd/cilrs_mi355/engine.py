@@ -120,6 +120,10 @@ class Plan:
     def profile_reset(self):
         L.check(L.lib().cilrs_net_profile_reset(self.handle))
 
+    def wino_convs(self) -> int:
+        """Convolutions of this plan's train step that run on the Winograd kernel (0: none)."""
+        return int(L.lib().cilrs_net_wino_convs(self.handle))
+
     def profile_table(self):
         lib = L.lib()
         L.check(lib.cilrs_net_profile_collect(self.handle))

@@ -1797,6 +1797,8 @@ int cilrs_net_b1_stage_us(cilrs_net* net, const cilrs_buffers* bufs, float* star
     return 0;
 }
 
+int cilrs_net_wino_convs(cilrs_net* net) { return net ? net->wino_table.n : 0; }
+
 int cilrs_net_b1_stages(cilrs_net* net) {
     if (!net || net->b1_table == 0) return 0;
     if (net->b1_blocks < 0) return -1;             // not launched yet

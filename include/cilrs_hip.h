@@ -224,6 +224,11 @@ int cilrs_net_forward_u8_b1_post(cilrs_net* net, const cilrs_buffers* bufs, cons
 int cilrs_net_forward_u8_b1_sync(cilrs_net* net, const cilrs_buffers* bufs, const uint8_t* frame,
                                  const float* speed, const int64_t* command, float* controls,
                                  float* pred_speed, void* stream);
+/* how many convolutions of this plan's TRAIN step run on the Winograd F(2x2,3x3) kernel (forward
+ * and data gradient each; csrc/conv_wino.hip): the stride-1 3x3 layers of an fp32 train plan with
+ * up to 256 channels and at least half a chip of 64-tile x 64-channel blocks.  CILRS_WINO=0 in the
+ * environment of the process turns the path off (0 here), CILRS_WINO=2 drops the block-count rule. */
+int cilrs_net_wino_convs(cilrs_net* net);
 /* number of stages (= grid barriers + 1) of that launch; -1 before the first call, 0 if the plan
  * has no persistent path */
 int cilrs_net_b1_stages(cilrs_net* net);

@@ -699,6 +699,12 @@ def test_train_step_b128_vs_oracle(cfg_name):
     # the step, piecewise through the same entry points train_step uses, to see its outputs
     m.train()
     controls, pred_speed, pl = eng.run_forward(*to_dev(imgs, spds, cmds), True, 0.0, 0)
+    # at this size the 24 stride-1 3x3 convolutions of layers 1-3 run on the Winograd kernel,
+    # forward and data gradient (unless the process was started with CILRS_WINO=0): this test is
+    # that path's whole-step parity check, so make sure it is the one that ran
+    import os
+    if os.environ.get("CILRS_WINO", "1") != "0":
+        assert pl.wino_convs() == 24, pl.wino_convs()
     _, dc, dp = tr.loss(controls, tgts.cuda(), pred_speed, spds.cuda())
     eng.run_backward(pl, dc, dp)
     tr.optimizer_step(1.0)
