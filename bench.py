@@ -399,7 +399,8 @@ def main():
             if key in tj:
                 out["roofline"]["traffic"] = tj[key]["bytes_per_launch"]
                 out["roofline"]["traffic_from"] = "profiles/traffic.json (" + tj.get(
-                    "source", "rocprofv3 --pmc passes") + ")"
+                    "source", "rocprofv3 --pmc passes") + "; measured on commit " + tj.get(
+                    "commit", "of round 2") + ")"
         out["kernels"] = {
             f: {"calls_per_step": a["calls"] // max(args.profile_steps, 1),
                 "ms_per_step": round(a["ms"] / args.profile_steps, 4),

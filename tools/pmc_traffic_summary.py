@@ -17,18 +17,24 @@ def load(sub, counter):
         if r["Counter_Name"] != counter:
             continue
         n = r["Kernel_Name"]
-        fam = "igemm" if "conv_igemm_kernel" in n else "wgrad" if "conv_wgrad_kernel" in n else None
-        if fam is None:
-            continue
-        a = agg.setdefault(fam, [0, 0.0])
-        a[0] += 1
-        a[1] += float(r["Counter_Value"])
+        # "igemm" = the forward + data-gradient family bench.py's roofline object is about: the
+        # implicit-GEMM kernel and (round 3) the Winograd kernel that took over layers 1-3; the two
+        # are also listed on their own
+        fams = ["igemm", "igemm_only"] if "conv_igemm_kernel" in n else \
+            ["igemm", "wino_only"] if "conv_wino_kernel" in n else \
+            ["wgrad"] if "conv_wgrad_kernel" in n else []
+        for fam in fams:
+            a = agg.setdefault(fam, [0, 0.0])
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
     return agg
 
 
 fe, wr = load("fetch", "FETCH_SIZE"), load("write", "WRITE_SIZE")
 res = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on `bench.py --steps 3 --warmup 1` "
-                 "(tools/pmc_traffic.sh); FETCH_SIZE x2 per the gfx950 correction; KiB -> bytes"}
+                 "(tools/pmc_traffic.sh); FETCH_SIZE x2 per the gfx950 correction; KiB -> bytes; "
+                 "igemm = forward + data-gradient family (conv_igemm_kernel + conv_wino_kernel)",
+       "commit": sys.argv[2] if len(sys.argv) > 2 else "unknown"}
 for fam in fe:
     n = fe[fam][0]
     rd = 2.0 * fe[fam][1] * 1024.0 / n
