@@ -114,9 +114,8 @@ __global__ __launch_bounds__(256) void bn_colreduce_kernel(
 // nblk = 2,200: nine dependent memory round trips.)
 constexpr int kFinThreads = 256;
 __device__ __forceinline__ bool partial_sums(const float* __restrict__ partial, const int nblk,
-                                             const int C, int& c, double& s1, double& s2) {
+                                             const int C, const int c, double& s1, double& s2) {
     __shared__ double red[2][kFinThreads / 64];
-    c = blockIdx.x;
     const float* r1 = partial + (size_t)c * nblk;
     const float* r2 = partial + (size_t)(C + c) * nblk;
     double p1 = 0.0, p2 = 0.0;
@@ -145,33 +144,135 @@ __device__ __forceinline__ bool partial_sums(const float* __restrict__ partial, 
     __syncthreads();
     s1 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
     s2 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    __syncthreads();                 // (callers may loop over channels: red is reused)
     return threadIdx.x == 0;
 }
 
+// ---- finalize inside the apply launch ------------------------------------------------------------
+// The per-channel finalize (a C-block launch of pure load latency, 5.4 us + the launch gap, 72 of
+// them per train step) runs as the FIRST job of the apply kernel instead.  The apply kernel is one
+// 1,024-thread workgroup per CU; workgroup b finalizes channels 4b .. 4b+3 (one per 256-thread
+// group, the same fixed-order double-precision tree as the stand-alone kernel), publishes the 3-4
+// coefficients with write-through (sc1) stores, drains them and arrives on one of 8 sharded device
+// counters (channel & 7, one 128-byte line each).  Every workgroup first puts its first elements
+// in flight, then ONE wave polls the 8 shards (8 lanes, sc1 loads) until they reach this launch's
+// target, and everybody reads the coefficients with sc1 loads -- the fence-free hand-off of
+// infer_b1.hip / cdna guide G16.  The counters are monotonic (the host passes the cumulative
+// target, compared wrap-safe), so nothing is reset on the device: a first version with one counter,
+// 1,024 polling workgroups and a departure counter for the reset cost +25 us per launch in
+// same-address atomics (profiles/r03_bn_fused.log).  No deadlock: the grid is at most one
+// workgroup per CU, all resident; the spin is bounded all the same, and a timeout poisons the
+// output with NaN (fails loudly in every parity test and in the loss).
+constexpr int kBnSpinLimit = 1 << 21;
+constexpr int kBnShardStride = 32;              // ints: one 128-byte line per shard
+constexpr int kApplyThreads = 1024;
+__device__ __forceinline__ void st_sc1(float* p, const float v) {
+    asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ int ld_int_sc1(const int* p) {
+    int v;
+    asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void publish_channel(int* sync, const int c) {   // the group's thread 0
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(&sync[(c & 7) * kBnShardStride], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// returns false on a timeout (block-uniform)
+__device__ __forceinline__ bool wait_channels(const int* sync, const int target) {
+    __shared__ int ok_s;
+    if (threadIdx.x < 64) {
+        int spins = 0, ok = 1;
+        while (true) {
+            int here = 1;
+            if (threadIdx.x < 8) here = (ld_int_sc1(&sync[threadIdx.x * kBnShardStride]) - target) >= 0;
+            if (__all(here)) break;
+            if (++spins > kBnSpinLimit) { ok = 0; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (threadIdx.x == 0) ok_s = ok;
+    }
+    __syncthreads();
+    return ok_s != 0;
+}
+// partial_sums for a 1,024-thread workgroup: 256-thread group g sums channel c (valid or not, all
+// groups run the same barriers); true for the group's first thread
+__device__ __forceinline__ bool partial_sums4(const float* __restrict__ partial, const int nblk,
+                                              const int C, const int c, const bool valid,
+                                              double& s1, double& s2) {
+    __shared__ double red4[2][kApplyThreads / 64];
+    const int t = threadIdx.x & 255, g = threadIdx.x >> 8;
+    const float* r1 = partial + (size_t)(valid ? c : 0) * nblk;
+    const float* r2 = partial + (size_t)(C + (valid ? c : 0)) * nblk;
+    double p1 = 0.0, p2 = 0.0;
+    for (int base = 0; base < nblk; base += 8 * 256) {
+        float v1[8], v2[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int b = base + t + 256 * u;
+            v1[u] = b < nblk ? r1[b] : 0.f;
+            v2[u] = b < nblk ? r2[b] : 0.f;
+        }
+        p1 += (((double)v1[0] + (double)v1[1]) + ((double)v1[2] + (double)v1[3])) +
+              (((double)v1[4] + (double)v1[5]) + ((double)v1[6] + (double)v1[7]));
+        p2 += (((double)v2[0] + (double)v2[1]) + ((double)v2[2] + (double)v2[3])) +
+              (((double)v2[4] + (double)v2[5]) + ((double)v2[6] + (double)v2[7]));
+    }
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) {
+        p1 += __shfl_xor(p1, sft);
+        p2 += __shfl_xor(p2, sft);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red4[0][threadIdx.x >> 6] = p1;
+        red4[1][threadIdx.x >> 6] = p2;
+    }
+    __syncthreads();
+    s1 = (red4[0][4 * g] + red4[0][4 * g + 1]) + (red4[0][4 * g + 2] + red4[0][4 * g + 3]);
+    s2 = (red4[1][4 * g] + red4[1][4 * g + 1]) + (red4[1][4 * g + 2] + red4[1][4 * g + 3]);
+    __syncthreads();
+    return t == 0 && valid;
+}
 // stats layout (floats): [0,C) mean | [C,2C) rstd | [2C,3C) w = gamma*rstd | [3C,4C) b = beta-mean*w
-__global__ __launch_bounds__(kFinThreads) void bn_fwd_finalize_kernel(
-    const float* __restrict__ partial, const int nblk, const int M, const int C,
+template <bool SC1>
+__device__ __forceinline__ void fwd_finalize_channel(
+    const float* __restrict__ partial, const int nblk, const int M, const int C, const int c,
     const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
     float* running_var, long long* nbt, const float momentum, const float eps,
     float* __restrict__ stats) {
-    int c;
     double s1, s2;
-    if (!partial_sums(partial, nblk, C, c, s1, s2)) return;
+    if (SC1 ? !partial_sums4(partial, nblk, C, c, c < C, s1, s2)
+            : !partial_sums(partial, nblk, C, c, s1, s2)) return;
     const double mean = s1 / M;
     double var = s2 / M - mean * mean;
     if (var < 0.0) var = 0.0;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     const float w = gamma[c] * rstd;
-    stats[c] = (float)mean;
-    stats[C + c] = rstd;
-    stats[2 * C + c] = w;
-    stats[3 * C + c] = beta[c] - (float)mean * w;
+    if (SC1) {
+        st_sc1(stats + c, (float)mean);
+        st_sc1(stats + C + c, rstd);
+        st_sc1(stats + 2 * C + c, w);
+        st_sc1(stats + 3 * C + c, beta[c] - (float)mean * w);
+    } else {
+        stats[c] = (float)mean;
+        stats[C + c] = rstd;
+        stats[2 * C + c] = w;
+        stats[3 * C + c] = beta[c] - (float)mean * w;
+    }
     if (running_mean) {
         const double unbiased = M > 1 ? var * ((double)M / (double)(M - 1)) : var;
         running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
         running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
     }
     if (nbt && c == 0) *nbt += 1;
+}
+__global__ __launch_bounds__(kFinThreads) void bn_fwd_finalize_kernel(
+    const float* __restrict__ partial, const int nblk, const int M, const int C,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
+    float* running_var, long long* nbt, const float momentum, const float eps,
+    float* __restrict__ stats) {
+    fwd_finalize_channel<false>(partial, nblk, M, C, blockIdx.x, gamma, beta, running_mean,
+                                running_var, nbt, momentum, eps, stats);
 }
 
 // eval mode: stats from the running statistics
@@ -238,20 +339,98 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     }
 }
 
+// finalize + apply in one launch (see "finalize inside the apply launch"); the grid stride is a
+// multiple of C/4, so a thread keeps its channel quad for the whole loop
+struct BnFinArgs {
+    const float* partial; int nblk; int M;
+    const float* gamma; const float* beta; float* running_mean; float* running_var;
+    long long* nbt; float momentum; float eps;
+    int* sync; int target;
+};
+__global__ __launch_bounds__(kApplyThreads) void bn_finalize_apply_kernel(
+    const BnFinArgs f, const float* __restrict__ y, float* __restrict__ stats,
+    const float* __restrict__ residual, float* __restrict__ z, const size_t total4, const int C,
+    const int relu, __bf16* __restrict__ z16) {
+    for (int base = blockIdx.x * 4; base < C; base += gridDim.x * 4) {       // block-uniform trips
+        const int c = base + (threadIdx.x >> 8);
+        fwd_finalize_channel<true>(f.partial, f.nblk, f.M, C, c, f.gamma, f.beta, f.running_mean,
+                                   f.running_var, f.nbt, f.momentum, f.eps, stats);
+        if ((threadIdx.x & 255) == 0 && c < C) publish_channel(f.sync, c);
+    }
+    const int cq = C >> 2;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int q = (int)(i % cq);
+    // kU elements per thread and trip, all loads of a trip issued before the first use (the
+    // kernel is pure HBM streaming: bytes in flight per CU set the rate); the first trip's loads
+    // are in flight while the channels arrive
+    constexpr int kU = 4;
+    f32x4 v[kU], r[kU];
+    auto load_trip = [&](const size_t base) {
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const size_t j = base + u * stride;
+            v[u] = r[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (j < total4) {
+                v[u] = *reinterpret_cast<const f32x4*>(y + j * 4);
+                if (residual) r[u] = *reinterpret_cast<const f32x4*>(residual + j * 4);
+            }
+        }
+    };
+    load_trip(i);
+    const bool ok = wait_channels(f.sync, f.target);
+    f32x4 w, b;
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(w), "=&v"(b) : "v"(stats + 2 * C + q * 4), "v"(stats + 3 * C + q * 4) : "memory");
+    if (!ok) w = f32x4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
+    while (i < total4) {
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const size_t j = i + u * stride;
+            if (j < total4) {
+                f32x4 o = v[u] * w + b;
+                if (residual) o += r[u];
+                if (relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+                }
+                *reinterpret_cast<f32x4*>(z + j * 4) = o;
+                if (z16) store_bf16x4(z16, j, o);
+            }
+        }
+        i += kU * stride;
+        if (i < total4) load_trip(i);
+    }
+}
+
 // coef layout: [0,C) c1 = gamma*rstd | [C,2C) c2 = sum(g)/M | [2C,3C) c3 = sum(g*xhat)/M
+template <bool SC1>
+__device__ __forceinline__ void bwd_finalize_channel(
+    const float* __restrict__ partial, const int nblk, const int M, const int C, const int c,
+    const float* __restrict__ gamma, const float* __restrict__ stats, float* dgamma,
+    float* dbeta, float* __restrict__ coef, const int accumulate) {
+    double s1, s2;
+    if (SC1 ? !partial_sums4(partial, nblk, C, c, c < C, s1, s2)
+            : !partial_sums(partial, nblk, C, c, s1, s2)) return;
+    const float db = (float)s1, dg = (float)s2;
+    dbeta[c] = accumulate ? dbeta[c] + db : db;
+    dgamma[c] = accumulate ? dgamma[c] + dg : dg;
+    if (SC1) {
+        st_sc1(coef + c, gamma[c] * stats[C + c]);
+        st_sc1(coef + C + c, (float)(s1 / M));
+        st_sc1(coef + 2 * C + c, (float)(s2 / M));
+    } else {
+        coef[c] = gamma[c] * stats[C + c];
+        coef[C + c] = (float)(s1 / M);
+        coef[2 * C + c] = (float)(s2 / M);
+    }
+}
 __global__ __launch_bounds__(kFinThreads) void bn_bwd_finalize_kernel(
     const float* __restrict__ partial, const int nblk, const int M, const int C,
     const float* __restrict__ gamma, const float* __restrict__ stats, float* dgamma,
     float* dbeta, float* __restrict__ coef, const int accumulate) {
-    int c;
-    double s1, s2;
-    if (!partial_sums(partial, nblk, C, c, s1, s2)) return;
-    const float db = (float)s1, dg = (float)s2;
-    dbeta[c] = accumulate ? dbeta[c] + db : db;
-    dgamma[c] = accumulate ? dgamma[c] + dg : dg;
-    coef[c] = gamma[c] * stats[C + c];
-    coef[C + c] = (float)(s1 / M);
-    coef[2 * C + c] = (float)(s2 / M);
+    bwd_finalize_channel<false>(partial, nblk, M, C, blockIdx.x, gamma, stats, dgamma, dbeta, coef,
+                                accumulate);
 }
 
 // g = dz * (z>0 if relu);  dy = (g - c2 - xhat*c3) * c1;  optionally g_out = g (residual path)
@@ -280,6 +459,72 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
         const f32x4 d = (g - c2 - xh * c3) * c1;
         if (dy) *reinterpret_cast<f32x4*>(dy + i * 4) = d;
         if (dy16) store_bf16x4(dy16, i, d);
+    }
+}
+
+struct BnBwdFinArgs {
+    const float* partial; int nblk; int M;
+    const float* gamma; float* dgamma; float* dbeta; int accumulate;
+    int* sync; int target;
+};
+__global__ __launch_bounds__(kApplyThreads) void bn_bwd_finalize_apply_kernel(
+    const BnBwdFinArgs f, const float* __restrict__ dz, const float* __restrict__ z,
+    const float* __restrict__ y, const float* __restrict__ stats, float* __restrict__ coef,
+    float* __restrict__ dy, float* __restrict__ g_out, const size_t total4, const int C,
+    const int relu, __bf16* __restrict__ dy16) {
+    for (int base = blockIdx.x * 4; base < C; base += gridDim.x * 4) {
+        const int c = base + (threadIdx.x >> 8);
+        bwd_finalize_channel<true>(f.partial, f.nblk, f.M, C, c, f.gamma, stats, f.dgamma, f.dbeta,
+                                   coef, f.accumulate);
+        if ((threadIdx.x & 255) == 0 && c < C) publish_channel(f.sync, c);
+    }
+    const int cq = C >> 2;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int q = (int)(i % cq);
+    const f32x4 mean = *reinterpret_cast<const f32x4*>(stats + q * 4);
+    const f32x4 rstd = *reinterpret_cast<const f32x4*>(stats + C + q * 4);
+    constexpr int kU = 3;
+    f32x4 g[kU], zz[kU], yy[kU];
+    auto load_trip = [&](const size_t base) {
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const size_t j = base + u * stride;
+            g[u] = zz[u] = yy[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (j < total4) {
+                g[u] = *reinterpret_cast<const f32x4*>(dz + j * 4);
+                if (relu) zz[u] = *reinterpret_cast<const f32x4*>(z + j * 4);
+                yy[u] = *reinterpret_cast<const f32x4*>(y + j * 4);
+            }
+        }
+    };
+    load_trip(i);
+    const bool ok = wait_channels(f.sync, f.target);
+    f32x4 c1, c2, c3;
+    asm volatile("global_load_dwordx4 %0, %3, off sc1\n\tglobal_load_dwordx4 %1, %4, off sc1\n\t"
+                 "global_load_dwordx4 %2, %5, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(c1), "=&v"(c2), "=&v"(c3)
+                 : "v"(coef + q * 4), "v"(coef + C + q * 4), "v"(coef + 2 * C + q * 4) : "memory");
+    if (!ok) c1 = f32x4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
+    while (i < total4) {
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const size_t j = i + u * stride;
+            if (j < total4) {
+                f32x4 gg = g[u];
+                if (relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) gg[e] = zz[u][e] > 0.f ? gg[e] : 0.f;
+                }
+                const f32x4 xh = (yy[u] - mean) * rstd;
+                if (g_out) *reinterpret_cast<f32x4*>(g_out + j * 4) = gg;
+                const f32x4 d = (gg - c2 - xh * c3) * c1;
+                if (dy) *reinterpret_cast<f32x4*>(dy + j * 4) = d;
+                if (dy16) store_bf16x4(dy16, j, d);
+            }
+        }
+        i += kU * stride;
+        if (i < total4) load_trip(i);
     }
 }
 
@@ -619,6 +864,18 @@ int grid_for(size_t total, int per_block = 256, int cap = 4096) {
     return (int)b;
 }
 
+// one 1,024-thread workgroup per CU: every workgroup of the finalize-inside-apply kernels is resident
+int apply_grid_cap() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 64;
+        cus = p.multiProcessorCount > 0 ? p.multiProcessorCount : 64;
+    }
+    return cus;
+}
+
 struct ColPlan { int nblk; int rows_per_block; };
 int col_groups(int C) { return C > 1024 ? C / 1024 : 1; }
 ColPlan col_plan(int M, int C) {
@@ -646,7 +903,7 @@ static int check_c(int C) {
 int launch_bn_train_fwd(const float* y, int M, int C, const float* gamma, const float* beta,
                         float* running_mean, float* running_var, long long* nbt, float momentum,
                         float eps, const float* residual, int relu, float* stats, float* partial,
-                        float* z, int pre_nblk, hipStream_t s, void* z16) {
+                        float* z, int pre_nblk, hipStream_t s, void* z16, BnSync* sync) {
     if (check_c(C)) return 1;
     int nblk = pre_nblk;
     if (nblk <= 0) {
@@ -655,6 +912,16 @@ int launch_bn_train_fwd(const float* y, int M, int C, const float* gamma, const 
                                                       0, p.rows_per_block);
         CILRS_LAUNCH_CHECK();
         nblk = p.nblk;
+    }
+    if (z && sync && sync->dev && C <= 1024 && C % 8 == 0) {   // finalize as the first job of the apply launch
+        const size_t total4 = (size_t)M * C / 4;
+        sync->total += C / 8;
+        const BnFinArgs f{partial, nblk, M, gamma, beta, running_mean, running_var, nbt, momentum, eps,
+                          sync->dev, sync->total};
+        bn_finalize_apply_kernel<<<grid_for(total4, kApplyThreads, apply_grid_cap()), kApplyThreads, 0, s>>>(
+            f, y, stats, residual, z, total4, C, relu, reinterpret_cast<__bf16*>(z16));
+        CILRS_LAUNCH_CHECK();
+        return 0;
     }
     bn_fwd_finalize_kernel<<<C, kFinThreads, 0, s>>>(partial, nblk, M, C, gamma, beta,
                                                         running_mean, running_var, nbt, momentum,
@@ -693,7 +960,7 @@ int launch_bn_eval_fwd(const float* y, int M, int C, const float* gamma, const f
 int launch_bn_bwd(const float* dz, const float* z, const float* y, int M, int C,
                   const float* gamma, const float* stats, int relu, float* dgamma, float* dbeta,
                   int accumulate, float* coef, float* partial, float* dy, float* g_out,
-                  int pre_nblk, hipStream_t s, void* dy16) {
+                  int pre_nblk, hipStream_t s, void* dy16, BnSync* sync) {
     if (check_c(C)) return 1;
     int nblk = pre_nblk;
     if (nblk <= 0) {
@@ -703,10 +970,18 @@ int launch_bn_bwd(const float* dz, const float* z, const float* y, int M, int C,
         CILRS_LAUNCH_CHECK();
         nblk = p.nblk;
     }
+    const size_t total4 = (size_t)M * C / 4;
+    if (sync && sync->dev && C <= 1024 && C % 8 == 0) {
+        sync->total += C / 8;
+        const BnBwdFinArgs f{partial, nblk, M, gamma, dgamma, dbeta, accumulate, sync->dev, sync->total};
+        bn_bwd_finalize_apply_kernel<<<grid_for(total4, kApplyThreads, apply_grid_cap()), kApplyThreads, 0, s>>>(
+            f, dz, z, y, stats, coef, dy, g_out, total4, C, relu, reinterpret_cast<__bf16*>(dy16));
+        CILRS_LAUNCH_CHECK();
+        return 0;
+    }
     bn_bwd_finalize_kernel<<<C, kFinThreads, 0, s>>>(partial, nblk, M, C, gamma, stats,
                                                         dgamma, dbeta, coef, accumulate);
     CILRS_LAUNCH_CHECK();
-    const size_t total4 = (size_t)M * C / 4;
     bn_bwd_apply_kernel<<<grid_for(total4), 256, 0, s>>>(dz, z, y, stats, coef, dy, g_out, total4,
                                                          C, relu, reinterpret_cast<__bf16*>(dy16));
     CILRS_LAUNCH_CHECK();

@@ -178,11 +178,19 @@ int launch_conv_wgrad(const WgradArgs& a, hipStream_t s);
 // ---- BatchNorm / pooling (bn_pool.hip) --------------------------------------------------------
 // stats: 4*C floats (mean | rstd | w | b); coef: 3*C floats; partial: bn_partial_floats(C) floats
 size_t bn_partial_floats(int C);
+// counters of the finalize-inside-apply launches: 8 shards x 32 ints of device memory, zero when
+// `total` is zero; the launchers advance `total` (cumulative arrivals per shard) -- one object per
+// stream of BatchNorm launches, never shared between two launches that may overlap
+struct BnSync { int* dev; int total; };
+constexpr int kBnSyncInts = 8 * 32;
 // pre_nblk > 0: `partial` already holds pre_nblk per-tile partial sums (fused into the conv)
 int launch_bn_train_fwd(const float* y, int M, int C, const float* gamma, const float* beta,
                         float* running_mean, float* running_var, long long* nbt, float momentum,
                         float eps, const float* residual, int relu, float* stats, float* partial,
-                        float* z, int pre_nblk, hipStream_t s, void* z16 = nullptr);
+                        float* z, int pre_nblk, hipStream_t s, void* z16 = nullptr,
+                        BnSync* sync = nullptr);
+// (sync != NULL: the per-channel finalize runs inside the apply launch instead of a launch of its
+//  own -- bn_pool.hip, "finalize inside the apply launch")
 // (z16 / dy16 / out16: optional bf16 shadow of the fp32 result -- the 16-bit operand of the next
 //  convolution in the bf16 training mode; launch_bn_bwd: dy may then be NULL)
 // eval-mode scale/shift of up to kMaxConvs BatchNorm layers in one launch (offsets in floats);
@@ -204,7 +212,7 @@ int launch_bn_eval_fwd(const float* y, int M, int C, const float* gamma, const f
 int launch_bn_bwd(const float* dz, const float* z, const float* y, int M, int C,
                   const float* gamma, const float* stats, int relu, float* dgamma, float* dbeta,
                   int accumulate, float* coef, float* partial, float* dy, float* g_out,
-                  int pre_nblk, hipStream_t s, void* dy16 = nullptr);
+                  int pre_nblk, hipStream_t s, void* dy16 = nullptr, BnSync* sync = nullptr);
 // stem: BatchNorm apply + ReLU + max-pool without materialising the post-BN tensor, and its backward
 int launch_bn_relu_maxpool_fwd(const float* y, const float* stats, float* out,
                                unsigned char* argmax, int N, int H, int W, int C, hipStream_t s,

@@ -263,7 +263,9 @@ struct cilrs_net {
     size_t x4, w4, pool, argmax_b /*bytes offset*/, combined, s1, p1, p2, h1[4], h2[4], all_out;
     size_t dcombined, ds1, dp1, dp2, dh1[4], dh2[4], dcomb_part[5], d_all, speed_in,
         cmd_b /*bytes offset*/;
-    size_t tile_cnt;                       // split-K ticket counters (ints)
+    size_t tile_cnt;                       // split-K ticket counters (ints), then 2 x kBnSyncInts ints:
+                                           // forward / backward finalize-in-apply counters
+    BnSync bn_sync[2] = {{nullptr, 0}, {nullptr, 0}};
     const void* cnt_zeroed_for = nullptr;  // workspace whose counters have been zeroed
     size_t G[kNumG];                       // gradient buffers: [1..3] fixed roles, the rest = dy ring
     size_t gmax;
@@ -356,11 +358,24 @@ struct Bump {
         }                                                                             \
     } while (0)
 
+static BnSync* bn_sync(cilrs_net* net, float* ws, int bwd);
 // split-K ticket counters start at zero; every reducer block re-zeroes its own afterwards
+// counters of the finalize-inside-apply BatchNorm launches (bn_pool.hip).  OFF by default: measured
+// at B=128 the in-launch hand-off (partials -> coefficients -> sc1 publish -> counter -> poll ->
+// sc1 read: four memory-side round trips) costs MORE than the 5.4 us finalize launch + its gap --
+// BatchNorm 1.33 ms/step with the separate launches, 1.70 ms fused (profiles/r03_bn_fused.log).
+// CILRS_BN_FUSED=1 selects it (tests/test_model_gpu.py runs one step that way).
+static BnSync* bn_sync(cilrs_net* net, float* ws, int bwd) {
+    static const int on = getenv("CILRS_BN_FUSED") ? atoi(getenv("CILRS_BN_FUSED")) : 0;
+    if (!on) return nullptr;
+    net->bn_sync[bwd].dev = reinterpret_cast<int*>(ws + net->tile_cnt) + kTileCounters + kBnSyncInts * bwd;
+    return &net->bn_sync[bwd];
+}
 int zero_counters_once(cilrs_net* net, void* workspace, hipStream_t s) {
     if (net->cnt_zeroed_for == workspace) return 0;
     float* ws = reinterpret_cast<float*>(workspace);
-    CILRS_HIP(hipMemsetAsync(ws + net->tile_cnt, 0, kTileCounters * sizeof(int), s));
+    CILRS_HIP(hipMemsetAsync(ws + net->tile_cnt, 0, (kTileCounters + 2 * kBnSyncInts) * sizeof(int), s));
+    net->bn_sync[0].total = net->bn_sync[1].total = 0;
     net->cnt_zeroed_for = workspace;
     return 0;
 }
@@ -848,7 +863,7 @@ int cilrs_net_create_ex(int variant, int batch, int height, int width, unsigned 
     n->ksplit_floats = ksplit_max;
     n->ksplit = bump.take(ksplit_max > 0 ? ksplit_max : 4);
     n->status_b = bump.take(64) * sizeof(float);
-    n->tile_cnt = bump.take(kTileCounters);
+    n->tile_cnt = bump.take(kTileCounters + 2 * kBnSyncInts);  // + the BatchNorm finalize counters
     CILRS_CHECK((int)A.convs.size() <= kMaxConvs, "too many convolutions for the BN tables");
     n->bn_table.n = (int)A.convs.size();
     for (size_t ci = 0; ci < A.convs.size(); ++ci) {
@@ -1031,7 +1046,8 @@ static int forward_from_x4(cilrs_net* net, const cilrs_buffers* bufs, const floa
                                     R + b.rv, reinterpret_cast<long long*>(bufs->bn_nbt) + c.bn,
                                     mom, eps, residual, relu, ws + g.stats, ws + net->bn_partial,
                                     ws + g.z, pre_nblk, s,
-                                    bf16t ? (void*)h16(ws, net->z16[ci]) : nullptr));
+                                    bf16t ? (void*)h16(ws, net->z16[ci]) : nullptr,
+                                    bn_sync(net, ws, 0)));
         } else {
             RUN(net, std::string("bn_fwd.") + kGroupName[c.group], 0.0, bytes, s,
                 launch_bn_eval_fwd(ws + g.y, g.M, c.cout, P + b.gamma, P + b.beta, R + b.rm,
@@ -1975,7 +1991,8 @@ int cilrs_net_backward(cilrs_net* net, const cilrs_buffers* bufs, const float* d
                                       ws + gl.stats, 1, Gp + bl.gamma, Gp + bl.beta, 0,
                                       ws + net->bn_coef, ws + net->bn_partial,
                                       bf16t ? nullptr : Ga, Gb, net->bwd_nblk_next, s,
-                                      bf16t ? (void*)h16(ws, net->G16[ga]) : nullptr));
+                                      bf16t ? (void*)h16(ws, net->G16[ga]) : nullptr,
+                                      bn_sync(net, ws, 1)));
                     net->bwd_nblk_next = 0;
                 }
                 // 2. walk the main branch backwards: dW_i (side), d(input of conv_i) -> Gc, then
@@ -1998,7 +2015,8 @@ int cilrs_net_backward(cilrs_net* net, const cilrs_buffers* bufs, const float* d
                                       ws + gp.stats, 1, Gp + bp.gamma, Gp + bp.beta, 0,
                                       ws + net->bn_coef, ws + net->bn_partial,
                                       bf16t ? nullptr : Ga, nullptr, nbp, s,
-                                      bf16t ? (void*)h16(ws, net->G16[ga]) : nullptr));
+                                      bf16t ? (void*)h16(ws, net->G16[ga]) : nullptr,
+                                      bn_sync(net, ws, 1)));
                 }
                 // 3. dW1 (side)
                 if (wgrad_side(c1, g1, xin, xin16, ga, Gp + c1.w)) return 1;
@@ -2021,7 +2039,8 @@ int cilrs_net_backward(cilrs_net* net, const cilrs_buffers* bufs, const float* d
                                       ws + gd.stats, 0, Gp + bd.gamma, Gp + bd.beta, 0,
                                       ws + net->bn_coef, ws + net->bn_partial,
                                       bf16t ? nullptr : Gdn, nullptr, 0, s,
-                                      bf16t ? (void*)h16(ws, net->G16[gdn]) : nullptr));
+                                      bf16t ? (void*)h16(ws, net->G16[gdn]) : nullptr,
+                                      bn_sync(net, ws, 1)));
                     if (wgrad_side(cd, gd, xin, xin16, gdn, Gp + cd.w)) return 1;
                     // 6. dx += dgrad(conv_d)
                     if (dgrad(blk.down, gdn, Gd, Gd, nullptr, nullptr)) return 1;
