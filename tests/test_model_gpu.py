@@ -1639,3 +1639,59 @@ def test_scheduler_step_follows_torch_steplr_for_20_epochs():
         sched.step()
         tr.scheduler_step()
     assert tr.epoch == 20 and tr.lr == CONFIG_B.lr * 0.25
+
+
+_ENV_STEP = r"""
+import sys, json
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+import torch
+from cilrs_mi355 import CILRS, Trainer, TrainConfig
+torch.manual_seed(0)
+m = CILRS().cuda()
+tr = Trainer(m, TrainConfig())
+B = int(sys.argv[3])
+g = torch.Generator(device="cpu").manual_seed(5)
+batch = [torch.randn(B, 3, 88, 200, generator=g).cuda(), torch.rand(B, generator=g).cuda(),
+         torch.randint(0, 4, (B,), generator=g).cuda(), torch.rand(B, 3, generator=g).cuda()]
+for _ in range(2):
+    tr.train_step(*batch)
+torch.cuda.synchronize()
+out = {"loss": tr.losses()["total"], "wino": tr.eng.plan(B, 88, 200).wino_convs(),
+       "params": [float(tr.eng.params.double().sum()), float(tr.eng.params.double().abs().sum())],
+       "bn": [float(tr.eng.bn.double().sum()), float(tr.eng.bn.double().abs().sum())]}
+print("RESULT " + json.dumps(out))
+"""
+
+
+def _env_step(env_extra, B):
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, "-c", _ENV_STEP,
+                        os.path.join(root, "cilrs-autonomous-driving-carla_amd"), root, str(B)],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1]
+    return json.loads(line[7:])
+
+
+def test_library_switches_keep_the_step(tmp_path):
+    """The process-wide switches that select another kernel for the same arithmetic -- CILRS_WINO=0
+    (implicit GEMM instead of Winograd on layers 1-3) and CILRS_BN_FUSED=1 (BatchNorm finalize
+    inside the apply launch, the measured-slower variant of profiles/r03_bn_fused.log) -- are read
+    once per process, so each runs two B=128 train steps in a child process; loss, parameter and
+    running-statistic checksums after the steps must agree with the default build of the step to
+    fp32 rounding of the sums (the kernels differ in summation order, not in what they compute)."""
+    base = _env_step({}, 128)
+    assert base["wino"] == 24
+    for env in ({"CILRS_WINO": "0"}, {"CILRS_BN_FUSED": "1"}):
+        got = _env_step(env, 128)
+        assert got["wino"] == (0 if "CILRS_WINO" in env else 24)
+        assert abs(got["loss"] - base["loss"]) <= 2e-4 * max(1.0, abs(base["loss"])), (env, got, base)
+        for k in ("params", "bn"):
+            for a, b in zip(got[k], base[k]):
+                assert abs(a - b) <= 2e-5 * max(1.0, abs(b)), (env, k, a, b)
