@@ -403,184 +403,6 @@ __global__ __launch_bounds__(kApplyThreads) void bn_finalize_apply_kernel(
     }
 }
 
-// ---- finalize RE-DERIVED by every workgroup of the apply launch -----------------------------------
-// When a layer has few partials per channel (layers 3-4 of the trunk: 16-42 row blocks of the
-// producing convolution, C x nblk x 8 bytes <= 128 KB) every workgroup of the apply kernel sums them
-// itself -- one wave per channel, lanes along the partials (coalesced rows of the channel-major
-// [2][C][nblk] image), a fixed double-precision shuffle tree, so all workgroups get bit-identical
-// coefficients -- and keeps w | b (forward) or c1 | c2 | c3 (backward) in LDS.  No hand-off between
-// workgroups at all; workgroup 0 also writes the statistics the later kernels read.  This removes
-// the finalize LAUNCH (5.4 us + the boundary) for ~40 of the 72 BatchNorm calls of a train step;
-// the in-launch publish / poll variant above was slower than the launch it removed.
-__device__ __forceinline__ void wave_sums(const float* __restrict__ partial, const int nblk, const int C,
-                                          const int c, double& s1, double& s2) {
-    const int lane = threadIdx.x & 63;
-    const float* r1 = partial + (size_t)c * nblk;
-    const float* r2 = partial + (size_t)(C + c) * nblk;
-    double p1 = 0.0, p2 = 0.0;
-    for (int b = lane; b < nblk; b += 64) {
-        p1 += (double)r1[b];
-        p2 += (double)r2[b];
-    }
-#pragma unroll
-    for (int sft = 32; sft > 0; sft >>= 1) {
-        p1 += __shfl_xor(p1, sft);
-        p2 += __shfl_xor(p2, sft);
-    }
-    s1 = p1; s2 = p2;
-}
-struct BnRedArgs {
-    const float* partial; int nblk; int M;
-    const float* gamma; const float* beta; float* running_mean; float* running_var;
-    long long* nbt; float momentum; float eps;
-};
-__global__ __launch_bounds__(kApplyThreads) void bn_rederive_apply_kernel(
-    const BnRedArgs f, const float* __restrict__ y, float* __restrict__ stats,
-    const float* __restrict__ residual, float* __restrict__ z, const size_t total4, const int C,
-    const int relu, __bf16* __restrict__ z16) {
-    extern __shared__ float wb[];                    // w[C] | b[C]
-    const int cq = C >> 2;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int q = (int)(i % cq);
-    constexpr int kU = 4;
-    f32x4 v[kU], r[kU];
-    auto load_trip = [&](const size_t base) {
-#pragma unroll
-        for (int u = 0; u < kU; ++u) {
-            const size_t j = base + u * stride;
-            v[u] = r[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (j < total4) {
-                v[u] = *reinterpret_cast<const f32x4*>(y + j * 4);
-                if (residual) r[u] = *reinterpret_cast<const f32x4*>(residual + j * 4);
-            }
-        }
-    };
-    load_trip(i);                                    // in flight under the sums
-    for (int c = threadIdx.x >> 6; c < C; c += kApplyThreads / 64) {
-        double s1, s2;
-        wave_sums(f.partial, f.nblk, C, c, s1, s2);
-        if ((threadIdx.x & 63) == 0) {
-            const double mean = s1 / f.M;
-            double var = s2 / f.M - mean * mean;
-            if (var < 0.0) var = 0.0;
-            const float rstd = (float)(1.0 / sqrt(var + (double)f.eps));
-            const float w = f.gamma[c] * rstd;
-            const float b = f.beta[c] - (float)mean * w;
-            wb[c] = w;
-            wb[C + c] = b;
-            if (blockIdx.x == 0) {
-                stats[c] = (float)mean;
-                stats[C + c] = rstd;
-                stats[2 * C + c] = w;
-                stats[3 * C + c] = b;
-                if (f.running_mean) {
-                    const double unbiased = f.M > 1 ? var * ((double)f.M / (double)(f.M - 1)) : var;
-                    f.running_mean[c] = (float)((1.0 - f.momentum) * f.running_mean[c] + f.momentum * mean);
-                    f.running_var[c] = (float)((1.0 - f.momentum) * f.running_var[c] + f.momentum * unbiased);
-                }
-                if (f.nbt && c == 0) *f.nbt += 1;
-            }
-        }
-    }
-    __syncthreads();
-    const f32x4 w = *reinterpret_cast<const f32x4*>(wb + q * 4);
-    const f32x4 b = *reinterpret_cast<const f32x4*>(wb + C + q * 4);
-    while (i < total4) {
-#pragma unroll
-        for (int u = 0; u < kU; ++u) {
-            const size_t j = i + u * stride;
-            if (j < total4) {
-                f32x4 o = v[u] * w + b;
-                if (residual) o += r[u];
-                if (relu) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
-                }
-                *reinterpret_cast<f32x4*>(z + j * 4) = o;
-                if (z16) store_bf16x4(z16, j, o);
-            }
-        }
-        i += kU * stride;
-        if (i < total4) load_trip(i);
-    }
-}
-struct BnBwdRedArgs {
-    const float* partial; int nblk; int M;
-    const float* gamma; float* dgamma; float* dbeta; int accumulate;
-};
-__global__ __launch_bounds__(kApplyThreads) void bn_bwd_rederive_apply_kernel(
-    const BnBwdRedArgs f, const float* __restrict__ dz, const float* __restrict__ z,
-    const float* __restrict__ y, const float* __restrict__ stats, float* __restrict__ coef,
-    float* __restrict__ dy, float* __restrict__ g_out, const size_t total4, const int C,
-    const int relu, __bf16* __restrict__ dy16) {
-    extern __shared__ float cf[];                    // c1[C] | c2[C] | c3[C]
-    const int cq = C >> 2;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int q = (int)(i % cq);
-    const f32x4 mean = *reinterpret_cast<const f32x4*>(stats + q * 4);
-    const f32x4 rstd = *reinterpret_cast<const f32x4*>(stats + C + q * 4);
-    constexpr int kU = 3;
-    f32x4 g[kU], zz[kU], yy[kU];
-    auto load_trip = [&](const size_t base) {
-#pragma unroll
-        for (int u = 0; u < kU; ++u) {
-            const size_t j = base + u * stride;
-            g[u] = zz[u] = yy[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (j < total4) {
-                g[u] = *reinterpret_cast<const f32x4*>(dz + j * 4);
-                if (relu) zz[u] = *reinterpret_cast<const f32x4*>(z + j * 4);
-                yy[u] = *reinterpret_cast<const f32x4*>(y + j * 4);
-            }
-        }
-    };
-    load_trip(i);
-    for (int c = threadIdx.x >> 6; c < C; c += kApplyThreads / 64) {
-        double s1, s2;
-        wave_sums(f.partial, f.nblk, C, c, s1, s2);
-        if ((threadIdx.x & 63) == 0) {
-            const float k1 = f.gamma[c] * stats[C + c];
-            const float k2 = (float)(s1 / f.M), k3 = (float)(s2 / f.M);
-            cf[c] = k1;
-            cf[C + c] = k2;
-            cf[2 * C + c] = k3;
-            if (blockIdx.x == 0) {
-                const float db = (float)s1, dg = (float)s2;
-                f.dbeta[c] = f.accumulate ? f.dbeta[c] + db : db;
-                f.dgamma[c] = f.accumulate ? f.dgamma[c] + dg : dg;
-                coef[c] = k1;
-                coef[C + c] = k2;
-                coef[2 * C + c] = k3;
-            }
-        }
-    }
-    __syncthreads();
-    const f32x4 c1 = *reinterpret_cast<const f32x4*>(cf + q * 4);
-    const f32x4 c2 = *reinterpret_cast<const f32x4*>(cf + C + q * 4);
-    const f32x4 c3 = *reinterpret_cast<const f32x4*>(cf + 2 * C + q * 4);
-    while (i < total4) {
-#pragma unroll
-        for (int u = 0; u < kU; ++u) {
-            const size_t j = i + u * stride;
-            if (j < total4) {
-                f32x4 gg = g[u];
-                if (relu) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) gg[e] = zz[u][e] > 0.f ? gg[e] : 0.f;
-                }
-                const f32x4 xh = (yy[u] - mean) * rstd;
-                if (g_out) *reinterpret_cast<f32x4*>(g_out + j * 4) = gg;
-                const f32x4 d = (gg - c2 - xh * c3) * c1;
-                if (dy) *reinterpret_cast<f32x4*>(dy + j * 4) = d;
-                if (dy16) store_bf16x4(dy16, j, d);
-            }
-        }
-        i += kU * stride;
-        if (i < total4) load_trip(i);
-    }
-}
-
 // coef layout: [0,C) c1 = gamma*rstd | [C,2C) c2 = sum(g)/M | [2C,3C) c3 = sum(g*xhat)/M
 template <bool SC1>
 __device__ __forceinline__ void bwd_finalize_channel(
@@ -1054,12 +876,6 @@ int apply_grid_cap() {
     return cus;
 }
 
-// few enough partials for every apply workgroup to sum them itself (CILRS_BN_REDERIVE=0: never)
-bool rederive_ok(int nblk, int C) {
-    static const int on = getenv("CILRS_BN_REDERIVE") ? atoi(getenv("CILRS_BN_REDERIVE")) : 1;
-    return on && nblk > 0 && nblk <= 256 && C <= 1024 && (size_t)nblk * C * 8 <= (size_t)on * 128 * 1024;
-}
-
 struct ColPlan { int nblk; int rows_per_block; };
 int col_groups(int C) { return C > 1024 ? C / 1024 : 1; }
 ColPlan col_plan(int M, int C) {
@@ -1096,15 +912,6 @@ int launch_bn_train_fwd(const float* y, int M, int C, const float* gamma, const 
                                                       0, p.rows_per_block);
         CILRS_LAUNCH_CHECK();
         nblk = p.nblk;
-    }
-    if (z && rederive_ok(nblk, C)) {          // every workgroup of the apply launch re-derives the coefficients
-        const size_t total4 = (size_t)M * C / 4;
-        const BnRedArgs f{partial, nblk, M, gamma, beta, running_mean, running_var, nbt, momentum, eps};
-        bn_rederive_apply_kernel<<<grid_for(total4, kApplyThreads, apply_grid_cap()), kApplyThreads,
-                                   2 * C * sizeof(float), s>>>(
-            f, y, stats, residual, z, total4, C, relu, reinterpret_cast<__bf16*>(z16));
-        CILRS_LAUNCH_CHECK();
-        return 0;
     }
     if (z && sync && sync->dev && C <= 1024 && C % 8 == 0) {   // finalize as the first job of the apply launch
         const size_t total4 = (size_t)M * C / 4;
@@ -1164,14 +971,6 @@ int launch_bn_bwd(const float* dz, const float* z, const float* y, int M, int C,
         nblk = p.nblk;
     }
     const size_t total4 = (size_t)M * C / 4;
-    if (rederive_ok(nblk, C)) {
-        const BnBwdRedArgs f{partial, nblk, M, gamma, dgamma, dbeta, accumulate};
-        bn_bwd_rederive_apply_kernel<<<grid_for(total4, kApplyThreads, apply_grid_cap()), kApplyThreads,
-                                       3 * C * sizeof(float), s>>>(
-            f, dz, z, y, stats, coef, dy, g_out, total4, C, relu, reinterpret_cast<__bf16*>(dy16));
-        CILRS_LAUNCH_CHECK();
-        return 0;
-    }
     if (sync && sync->dev && C <= 1024 && C % 8 == 0) {
         sync->total += C / 8;
         const BnBwdFinArgs f{partial, nblk, M, gamma, dgamma, dbeta, accumulate, sync->dev, sync->total};

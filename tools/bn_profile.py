@@ -29,4 +29,4 @@ for k, r in sorted(t.items()):
     if k.startswith("bn_"):
         tot += r["ms"] / 5
         print(f"{k:20s} calls/step {r['calls'] // 5:3d}  us/call {r['ms'] / r['calls'] * 1e3:7.2f}")
-print(f"BatchNorm total {tot:.3f} ms/step  (CILRS_BN_FUSED={os.environ.get('CILRS_BN_FUSED', '1')})")
+print(f"BatchNorm total {tot:.3f} ms/step  (CILRS_BN_FUSED={os.environ.get('CILRS_BN_FUSED', '0')})")
