@@ -303,13 +303,19 @@ struct WinoArgs {
     const float* bwd_z; const float* bwd_y; const float* bwd_stats; int bwd_relu;
     float* bwd_partial;
     long long* stamps;       // diagnostics: block 0's waves 0 / 4 write 2 x 8 cycle counts (NULL: off)
+    // filled in by launch_conv_wino (a launch = full 64-tile blocks + a tail of 16-tile blocks):
+    int no_tail;             // caller: 1 = all tiles on the 64-tile kernel (one launch)
+    int tile_begin;          // first output tile of this kernel's block 0
+    int row0, rows;          // column-partial row of block 0 / rows of the whole launch
 };
 size_t wino_weight_floats(int K, int C);
 // U from OHWI weights w[K][3][3][C]; dgrad = 1: the filter of the data gradient (taps flipped,
 // channel roles swapped: reduction over K, C output channels)
 int launch_wino_weights(const float* w, float* U, int K, int C, int dgrad, hipStream_t s);
 bool wino_supported(int C, int K, int ksize, int stride, int pad);
-int wino_groups(int N, int H, int W);        // column-partial rows a launch writes
+int wino_groups(int N, int H, int W);        // 64-tile groups of a launch
+// column-partial rows launch_conv_wino writes for these sizes (full groups + 16-tile tail groups)
+int wino_rows(int N, int H, int W, int K, int no_tail = 0);
 int launch_conv_wino(const WinoArgs& a, hipStream_t s);
 int wino_prepare();                          // one-time kernel attribute (call outside stream capture)
 // Both filter forms of every Winograd convolution of a network in ONE launch (the weights change

@@ -181,7 +181,7 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
     const int g_tile = (tid >> 2) & 63, g_p = tid & 3;
     unsigned voff[16];
     {
-        const int t = blk_m * WT + g_tile;
+        const int t = a.tile_begin + blk_m * WT + g_tile;
         const bool tv = t < total_tiles && gatherer;
         const int n = tv ? t / tiles_img : 0, rem = t - n * tiles_img;
         const int ty = rem / TW, tx = rem - ty * TW;
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
     const long long tm_loop1 = stamp ? __builtin_amdgcn_s_memtime() : 0;
 
     // ---- epilogue: this lane's tile (one per lane) and its 2 x 4 consecutive channels ----
-    const int t = blk_m * WT + tg * 16 + l15;
+    const int t = a.tile_begin + blk_m * WT + tg * 16 + l15;
     const bool tv = t < total_tiles;
     const int n = tv ? t / tiles_img : 0, rem = t - n * tiles_img;
     const int ty = rem / TW, tx = rem - ty * TW;
@@ -466,8 +466,264 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
 #pragma unroll 8
             for (int q = 0; q < 64; ++q) s += red[(which * 64 + q) * 64 + col];
             float* dst = stats_fwd ? a.bn_partial : a.bwd_partial;
-            const int groups = gridDim.x / nkt;
-            dst[(size_t)(which * a.K + k0 + col) * groups + blk_m] = s;
+            dst[(size_t)(which * a.K + k0 + col) * a.rows + a.row0 + blk_m] = s;
+        }
+    }
+}
+
+// ---- the tail of a launch: 16 tiles x 64 channels per block, producer / consumer waves ------------
+// A launch of the kernel above is N x tiles / 64 blocks of ~25-85 us on 256 CUs: layer1 needs 2.15
+// rounds and pays 3, layer2 1.22 and pays 2.  The blocks of the last, mostly empty round are cut
+// into four: this kernel gives a CU a quarter of a block's tiles (so four times as many CUs share
+// the round) and runs them in about a third of a block's time.  Waves 0-3 only multiply (16 tiles x
+// 16 channels x all 16 positions each, 64 accumulator registers); waves 4-7 only produce: wave 4
+// gathers + transforms the patch, all four stream the U chunk (the same 32 KB as a full block --
+// which is why this is the tail's kernel, not everybody's: at 16 tiles per block the L2 -> LDS
+// stream of U, 27 B/clk per CU, is the bound).  Producers run TWO chunks ahead in two register
+// sets (they have no accumulators); two LDS stages (80 KB), one barrier per chunk.
+constexpr int QT = 16;
+constexpr int QSTAGE = 16 * QT * WP + 16 * WK * WP;          // floats per stage (40 KB)
+constexpr size_t kWinoQLds = (size_t)2 * QSTAGE * sizeof(float);
+__global__ __launch_bounds__(WTHREADS) void conv_wino_q_kernel(const WinoArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Vs = smem;                          // [2 stages]: [16][QT][WP] | [16][WK][WP]
+    float* Us = smem + 16 * QT * WP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const bool consumer = wave < 4;
+    const int TH = (a.H + 1) >> 1, TW = (a.W + 1) >> 1;
+    const int tiles_img = TH * TW, total_tiles = a.N * tiles_img;
+    const int nkt = a.K / WK;
+    const int blk_n = blockIdx.x % nkt, blk_m = blockIdx.x / nkt;
+    const int k0 = blk_n * WK;
+    const int nchunks = a.C / WC;
+    const int tile0 = a.tile_begin + blk_m * QT;
+
+    // ---- producers ----
+    const int ptid = tid - 256;                               // 0..255 for waves 4-7
+    const bool gatherer = wave == 4;
+    const int g_tile = (ptid >> 2) & 15, g_p = ptid & 3;
+    unsigned voff[16];
+    {
+        const int t = tile0 + g_tile;
+        const bool tv = gatherer && t < total_tiles;
+        const int n = tv ? t / tiles_img : 0, rem = t - n * tiles_img;
+        const int ty = rem / TW, tx = rem - ty * TW;
+        const int h0 = 2 * ty - 1, w0 = 2 * tx - 1;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const int h = h0 + (p >> 2), w = w0 + (p & 3);
+            const bool ok = tv && h >= 0 && w >= 0 && h < a.H && w < a.W;
+            voff[p] = ok ? (unsigned)((((n * a.H + h) * a.W + w) * a.C + g_p * 2) * 4) : 0xFFFFFFFFu;
+        }
+    }
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.x, 0, (int)(unsigned)((size_t)a.N * a.H * a.W * a.C * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.U, 0, (int)(unsigned)((size_t)16 * a.C * a.K * 4), 0x00020000);
+    // U chunk = 2,048 float4: producer thread p takes float4 p + 256 j (j < 8): xi = 2 j + (p >> 7),
+    // float4 p & 127 of the xi's contiguous [64 k][8 c] slice
+    const int u_idx = ptid & 127, u_xi0 = (ptid >> 7) & 1;
+    auto load_set = [&](f32x2(&d)[16], f32x4(&u)[8], const int ch) {
+        const int soff = ch * WC * 4;
+        if (gatherer) {
+#pragma unroll
+            for (int p = 0; p < 16; ++p)
+                d[p] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsX, (int)voff[p], soff, 0));
+        }
+        const int usoff = (ch * a.K + k0) * 32;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int xi = 2 * j + u_xi0;
+            const unsigned off = (unsigned)(xi * nchunks * a.K * 8 + u_idx * 4) * 4u;
+            u[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsU, (int)off, usoff, 0));
+        }
+    };
+    auto store_set = [&](f32x2(&d)[16], const f32x4(&u)[8], const int stage) {
+        if (gatherer) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x2 r0 = d[0 * 4 + j] - d[2 * 4 + j];
+                const f32x2 r1 = d[1 * 4 + j] + d[2 * 4 + j];
+                const f32x2 r2 = d[2 * 4 + j] - d[1 * 4 + j];
+                const f32x2 r3 = d[1 * 4 + j] - d[3 * 4 + j];
+                d[0 * 4 + j] = r0; d[1 * 4 + j] = r1; d[2 * 4 + j] = r2; d[3 * 4 + j] = r3;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x2 v0 = d[i * 4 + 0] - d[i * 4 + 2];
+                const f32x2 v1 = d[i * 4 + 1] + d[i * 4 + 2];
+                const f32x2 v2 = d[i * 4 + 2] - d[i * 4 + 1];
+                const f32x2 v3 = d[i * 4 + 1] - d[i * 4 + 3];
+                float* dst = Vs + stage * QSTAGE + (i * 4) * (QT * WP) + g_tile * WP + g_p * 2;
+                *reinterpret_cast<f32x2*>(dst + 0 * QT * WP) = v0;
+                *reinterpret_cast<f32x2*>(dst + 1 * QT * WP) = v1;
+                *reinterpret_cast<f32x2*>(dst + 2 * QT * WP) = v2;
+                *reinterpret_cast<f32x2*>(dst + 3 * QT * WP) = v3;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            *reinterpret_cast<f32x4*>(Us + stage * QSTAGE + (2 * j + u_xi0) * (WK * WP) + u_idx * 4) = u[j];
+    };
+
+    // ---- consumers: rows = 16 channels (k0 + 16 wave ..), columns = the 16 tiles ----
+    f32x4 acc[16];
+#pragma unroll
+    for (int x = 0; x < 16; ++x) acc[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frag_v = l15 * WP + lq * 2;
+    const int frag_u = ((wave & 3) * 16 + l15) * WP + lq * 2;
+    auto multiply = [&](const int ch) {
+        const float* Vc = Vs + (ch & 1) * QSTAGE + frag_v;
+        const float* Uc = Us + (ch & 1) * QSTAGE + frag_u;
+        // pairs of positions, k-steps interleaved: consecutive MFMAs never share an accumulator
+        // (40-cycle dependent latency against a 32-cycle issue); reads run two pairs ahead
+        constexpr int D = 2;
+        f32x2 bv[D + 1][2], av[D + 1][2];
+#pragma unroll
+        for (int q = 0; q < D; ++q)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                bv[q][e] = *reinterpret_cast<const f32x2*>(Vc + (2 * q + e) * (QT * WP));
+                av[q][e] = *reinterpret_cast<const f32x2*>(Uc + (2 * q + e) * (WK * WP));
+            }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int cur = q % (D + 1), nxt = (q + D) % (D + 1);
+            if (q + D < 8) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    bv[nxt][e] = *reinterpret_cast<const f32x2*>(Vc + (2 * (q + D) + e) * (QT * WP));
+                    av[nxt][e] = *reinterpret_cast<const f32x2*>(Uc + (2 * (q + D) + e) * (WK * WP));
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+                    acc[2 * q + e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][e][s], bv[cur][e][s],
+                                                                         acc[2 * q + e], 0, 0, 0);
+            if (q + D < 8) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        }
+    };
+
+    f32x2 dA[16], dB[16];
+    f32x4 uA[8], uB[8];
+    if (!consumer) {
+        load_set(dA, uA, 0);
+        if (nchunks > 1) load_set(dB, uB, 1);
+        store_set(dA, uA, 0);
+        if (nchunks > 2) load_set(dA, uA, 2);
+    }
+    __syncthreads();
+    // iteration ch: consumers multiply stage ch & 1; producers store chunk ch + 1 (loaded two
+    // iterations ago) into the other stage and put chunk ch + 3 in flight in the set just freed
+    for (int ch = 0; ch < nchunks; ch += 2) {
+        if (consumer) {
+            multiply(ch);
+        } else if (ch + 1 < nchunks) {
+            store_set(dB, uB, 1);
+            if (ch + 3 < nchunks) load_set(dB, uB, ch + 3);
+        }
+        __syncthreads();
+        if (ch + 1 < nchunks) {
+            if (consumer) {
+                multiply(ch + 1);
+            } else if (ch + 2 < nchunks) {
+                store_set(dA, uA, 0);
+                if (ch + 4 < nchunks) load_set(dA, uA, ch + 4);
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue (consumers): this lane's tile and 4 consecutive channels ----
+    const bool stats_fwd = a.bn_partial != nullptr, stats_bwd = a.bwd_partial != nullptr;
+    f32x4 cs1 = f32x4{0.f, 0.f, 0.f, 0.f}, cs2 = cs1;
+    if (consumer) {
+        const int t = tile0 + l15;
+        const bool tv = t < total_tiles;
+        const int n = tv ? t / tiles_img : 0, rem = t - n * tiles_img;
+        const int ty = rem / TW, tx = rem - ty * TW;
+        const int co = k0 + wave * 16 + lq * 4;
+        const int yrec = (int)(unsigned)((size_t)a.N * a.H * a.W * a.K * 4);
+        const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, yrec, 0x00020000);
+        unsigned yoff[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int oy = 2 * ty + (q >> 1), ox = 2 * tx + (q & 1);
+            const bool ok = tv && oy < a.H && ox < a.W;
+            yoff[q] = ok ? (unsigned)((((n * a.H + oy) * a.W + ox) * a.K + co) * 4) : 0xFFFFFFFFu;
+        }
+        f32x4 ad[4];
+        if (a.addend) {
+            const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.addend, 0, yrec, 0x00020000);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                ad[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)yoff[q], 0, 0));
+        }
+        f32x4 s0[4], s1[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            s0[q] = acc[0 * 4 + q] + acc[1 * 4 + q] + acc[2 * 4 + q];
+            s1[q] = acc[1 * 4 + q] - acc[2 * 4 + q] - acc[3 * 4 + q];
+        }
+        f32x4 y[4];
+        y[0] = s0[0] + s0[1] + s0[2];
+        y[1] = s0[1] - s0[2] - s0[3];
+        y[2] = s1[0] + s1[1] + s1[2];
+        y[3] = s1[1] - s1[2] - s1[3];
+        if (a.addend) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) y[q] += ad[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4w, y[q]), rsY, (int)yoff[q], 0, 0);
+        if (stats_fwd) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = yoff[q] != 0xFFFFFFFFu ? y[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+                cs1 += v;
+                cs2 += v * v;
+            }
+        } else if (stats_bwd) {
+            const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc((void*)a.bwd_z, 0, yrec, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.bwd_y, 0, yrec, 0x00020000);
+            const f32x4 bmean = *reinterpret_cast<const f32x4*>(a.bwd_stats + co);
+            const f32x4 brstd = *reinterpret_cast<const f32x4*>(a.bwd_stats + a.K + co);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 zz = f32x4{1.f, 1.f, 1.f, 1.f};
+                if (a.bwd_relu)
+                    zz = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsZ, (int)yoff[q], 0, 0));
+                const f32x4 yy = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)yoff[q], 0, 0));
+                const bool ok = yoff[q] != 0xFFFFFFFFu;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float g = (ok && zz[e] > 0.f) ? y[q][e] : 0.f;
+                    cs1[e] += g;
+                    cs2[e] = fmaf(g, (yy[e] - bmean[e]) * brstd[e], cs2[e]);
+                }
+            }
+        }
+    }
+    if (stats_fwd || stats_bwd) {
+        float* red = smem;                      // [2 which][16 tiles][64 channels] (the K loop ended on a barrier)
+        if (consumer) {
+            const int c = wave * 16 + lq * 4;
+            *reinterpret_cast<f32x4*>(red + (0 * QT + l15) * 64 + c) = cs1;
+            *reinterpret_cast<f32x4*>(red + (1 * QT + l15) * 64 + c) = cs2;
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const int which = tid >> 6, col = tid & 63;
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < QT; ++q) s += red[(which * QT + q) * 64 + col];
+            float* dst = stats_fwd ? a.bn_partial : a.bwd_partial;
+            dst[(size_t)(which * a.K + k0 + col) * a.rows + a.row0 + blk_m] = s;
         }
     }
 }
@@ -507,12 +763,45 @@ int wino_prepare() {
     if (!attr_set) {
         CILRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoLds));
+        CILRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_q_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoQLds));
         attr_set = true;
     }
     return 0;
 }
 
-int launch_conv_wino(const WinoArgs& a, hipStream_t s) {
+// How a launch is cut: `full` 64-tile groups on the main kernel, the remaining tiles as 16-tile
+// groups on the tail kernel.  The tail takes the blocks of the last round when that round is at
+// most a quarter full (so that its four-times-as-many blocks still fit one round); CILRS_WINO_TAIL=0
+// never, =2 everything on the 16-tile kernel (experiments).
+struct WinoSplit { int full, tail; };
+static WinoSplit wino_split(int N, int H, int W, int K, int no_tail) {
+    static const int mode = getenv("CILRS_WINO_TAIL") ? atoi(getenv("CILRS_WINO_TAIL")) : 1;
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess &&
+               p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+    }
+    const int tiles = N * ((H + 1) / 2) * ((W + 1) / 2);
+    const int groups = cdiv(tiles, WT), nkt = K / WK;
+    WinoSplit sp{groups, 0};
+    if (mode == 2) sp.full = 0;
+    else if (mode == 1 && !no_tail) {
+        const int blocks = groups * nkt, last = blocks % cus;
+        if (blocks > cus && last > 0 && 4 * last <= cus) sp.full = (blocks - last) / nkt;
+    }
+    sp.tail = cdiv(tiles - sp.full * WT > 0 ? tiles - sp.full * WT : 0, QT);
+    return sp;
+}
+int wino_rows(int N, int H, int W, int K, int no_tail) {
+    const WinoSplit sp = wino_split(N, H, W, K, no_tail);
+    return sp.full + sp.tail;
+}
+
+int launch_conv_wino(const WinoArgs& a_in, hipStream_t s) {
+    WinoArgs a = a_in;
     CILRS_CHECK(a.x && a.U && a.y, "conv_wino: NULL tensor");
     CILRS_CHECK(a.C % WC == 0 && a.K % WK == 0, "conv_wino: C %% 8, K %% 64");
     CILRS_CHECK((size_t)a.N * a.H * a.W * a.C * 4 < (1ull << 32) &&
@@ -520,9 +809,19 @@ int launch_conv_wino(const WinoArgs& a, hipStream_t s) {
                 "conv_wino: tensor too large for 32-bit offsets");
     CILRS_CHECK(!(a.bn_partial && a.bwd_partial), "conv_wino: one kind of column partials per launch");
     if (wino_prepare()) return 1;
-    const int groups = wino_groups(a.N, a.H, a.W);
-    conv_wino_kernel<<<groups * (a.K / WK), WTHREADS, kWinoLds, s>>>(a);
-    CILRS_LAUNCH_CHECK();
+    const WinoSplit sp = wino_split(a.N, a.H, a.W, a.K, a.no_tail);
+    a.rows = sp.full + sp.tail;
+    if (sp.full > 0) {
+        a.tile_begin = 0; a.row0 = 0;
+        conv_wino_kernel<<<sp.full * (a.K / WK), WTHREADS, kWinoLds, s>>>(a);
+        CILRS_LAUNCH_CHECK();
+    }
+    if (sp.tail > 0) {
+        a.tile_begin = sp.full * WT; a.row0 = sp.full;
+        a.stamps = nullptr;
+        conv_wino_q_kernel<<<sp.tail * (a.K / WK), WTHREADS, kWinoQLds, s>>>(a);
+        CILRS_LAUNCH_CHECK();
+    }
     return 0;
 }
 

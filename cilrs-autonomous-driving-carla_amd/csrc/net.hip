@@ -398,12 +398,14 @@ int ensure_streams(cilrs_net* net) {
     return 0;
 }
 // concurrency is switched off while per-kernel timing is on (serial brackets are meaningful)
-bool use_overlap(cilrs_net* net) {
+// (the CONFIGURED state: what an unprofiled step of this plan does)
+bool overlap_configured(cilrs_net* net) {
     // CILRS_OVERLAP=0 serialises everything on the caller's stream (rocprofv3 per-kernel durations
     // then match the hipEvent brackets of the profile mode)
     static const int env = getenv("CILRS_OVERLAP") ? atoi(getenv("CILRS_OVERLAP")) : 1;
-    return env != 0 && net->overlap && !net->prof.on;
+    return env != 0 && net->overlap;
 }
+bool use_overlap(cilrs_net* net) { return overlap_configured(net) && !net->prof.on; }
 hipStream_t side_or(cilrs_net* net, hipStream_t main, int i) {
     return use_overlap(net) ? net->side[i] : main;
 }
@@ -448,7 +450,7 @@ int conv_fwd(cilrs_net* net, const ConvT& c, const ConvG& g, const float* x, int
         wa.x = x; wa.U = ws + net->wino_base + net->wino_table.u[e]; wa.y = y;
         wa.N = net->B; wa.H = g.H; wa.W = g.W; wa.C = c.cin; wa.K = c.cout;
         wa.bn_partial = ws + net->bn_partial;
-        *bn_nblk = wino_groups(net->B, g.H, g.W);
+        *bn_nblk = wino_rows(net->B, g.H, g.W, c.cout);
         const double flops = 2.0 * g.M * c.cout * c.k * c.k * c.cin;      // DIRECT-convolution flops
         const double bytes = 4.0 * ((double)net->B * g.H * g.W * c.cin + (double)g.M * c.cout +
                                     16.0 * c.cout * c.cin);
@@ -493,11 +495,18 @@ int conv_dgrad(cilrs_net* net, const ConvT& c, const ConvG& g, const float* dy, 
         while (net->wino_table.w[e] != (unsigned)c.w) ++e;
         wa.x = dy; wa.U = ws + net->wino_base + net->wino_table.ud[e]; wa.y = dx; wa.addend = addend;
         wa.N = net->B; wa.H = g.H; wa.W = g.W; wa.C = c.cout; wa.K = c.cin;
+        // the 16-tile tail launch pays in the forward pass only: in the backward pass the weight
+        // gradients of the side stream already fill the CUs a last round leaves idle, and a
+        // second launch per data gradient costs more in boundaries than it gains (step 11.09 vs
+        // 10.99 ms with tails on both sides, profiles/r03_wino_tail.log)
+        // (decided by the plan's configuration, not by whether this step is being profiled: the
+        //  profiled steps of bench.py must run the kernels the timed steps ran)
+        wa.no_tail = overlap_configured(net) ? 1 : 0;
         if (bwd_nblk) *bwd_nblk = 0;
         if (bn_of && bwd_nblk) {
             wa.bwd_z = ws + bn_of->z; wa.bwd_y = ws + bn_of->y; wa.bwd_stats = ws + bn_of->stats;
             wa.bwd_relu = bn_relu; wa.bwd_partial = ws + net->bn_partial;
-            *bwd_nblk = wino_groups(net->B, g.H, g.W);
+            *bwd_nblk = wino_rows(net->B, g.H, g.W, c.cin, wa.no_tail);
         }
         const double flops = 2.0 * g.M * c.cout * c.k * c.k * c.cin;
         const double bytes = 4.0 * ((double)net->B * g.H * g.W * c.cin + (double)g.M * c.cout +

@@ -640,7 +640,10 @@ def _grad_budget_check(tag, named_oracle_params, gv, g64, coef, cos_floor=1e-5, 
             e_alt = [float((a - ref64).norm()) / nrm for a in alts]
             spread = max(float((alts[i] - alts[j]).norm()) / nrm
                          for i in range(len(alts)) for j in range(i))
-            floor = max(max(e_alt), spread)
+            # (never below a few fp32 ulps: the four CPU realisations of a ONE-element tensor such as
+            #  speed_predictor.5.bias can agree bit for bit at 1.2e-8 from float64 while a different
+            #  but equally legal summation order lands one ulp away, 6.6e-8)
+            floor = max(max(e_alt), spread, 2.5e-7)
             ratios.append((e_gpu / max(floor, 1e-12), n))
             assert e_gpu <= max(4.0 * e_cpu, 4.0 * floor), (tag, n, e_gpu, e_alt, spread)
         gmax = max(float(ref64.abs().max()), 1e-12)
@@ -1657,6 +1660,7 @@ for _ in range(2):
     tr.train_step(*batch)
 torch.cuda.synchronize()
 out = {"loss": tr.losses()["total"], "wino": tr.eng.plan(B, 88, 200).wino_convs(),
+       "n": int(tr.eng.params.numel()), "lr": float(tr.cfg.lr),
        "params": [float(tr.eng.params.double().sum()), float(tr.eng.params.double().abs().sum())],
        "bn": [float(tr.eng.bn.double().sum()), float(tr.eng.bn.double().abs().sum())]}
 print("RESULT " + json.dumps(out))
@@ -1683,15 +1687,20 @@ def test_library_switches_keep_the_step(tmp_path):
     """The process-wide switches that select another kernel for the same arithmetic -- CILRS_WINO=0
     (implicit GEMM instead of Winograd on layers 1-3) and CILRS_BN_FUSED=1 (BatchNorm finalize
     inside the apply launch, the measured-slower variant of profiles/r03_bn_fused.log) -- are read
-    once per process, so each runs two B=128 train steps in a child process; loss, parameter and
-    running-statistic checksums after the steps must agree with the default build of the step to
-    fp32 rounding of the sums (the kernels differ in summation order, not in what they compute)."""
+    once per process, so each runs two B=128 train steps in a child process.  The loss of the second
+    step and the BatchNorm running-statistic checksums must agree with the default kernels to fp32
+    rounding (the kernels differ in summation order, not in what they compute); the parameter
+    checksums within what the one-step parameter gate allows for two implementations of the same
+    step (_close_params: at most OUTLIER_FRAC_1 of the elements off by up to 2.2 lr per step, where
+    Adam's lr * sign-like update is decided by a gradient inside fp32 noise of zero)."""
     base = _env_step({}, 128)
     assert base["wino"] == 24
     for env in ({"CILRS_WINO": "0"}, {"CILRS_BN_FUSED": "1"}):
         got = _env_step(env, 128)
         assert got["wino"] == (0 if "CILRS_WINO" in env else 24)
         assert abs(got["loss"] - base["loss"]) <= 2e-4 * max(1.0, abs(base["loss"])), (env, got, base)
-        for k in ("params", "bn"):
-            for a, b in zip(got[k], base[k]):
-                assert abs(a - b) <= 2e-5 * max(1.0, abs(b)), (env, k, a, b)
+        for a, b in zip(got["bn"], base["bn"]):
+            assert abs(a - b) <= 2e-5 * max(1.0, abs(b)), (env, "bn", a, b)
+        budget = base["n"] * OUTLIER_FRAC_1 * 2.2 * base["lr"] * 2
+        for a, b in zip(got["params"], base["params"]):
+            assert abs(a - b) <= budget, (env, "params", a, b, budget)
