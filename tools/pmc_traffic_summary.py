@@ -21,7 +21,7 @@ def load(sub, counter):
         # implicit-GEMM kernel and (round 3) the Winograd kernel that took over layers 1-3; the two
         # are also listed on their own
         fams = ["igemm", "igemm_only"] if "conv_igemm_kernel" in n else \
-            ["igemm", "wino_only"] if "conv_wino_kernel" in n else \
+            ["igemm", "wino_only"] if "conv_wino" in n else \
             ["wgrad"] if "conv_wgrad_kernel" in n else []
         for fam in fams:
             a = agg.setdefault(fam, [0, 0.0])
