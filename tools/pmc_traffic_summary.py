@@ -11,7 +11,8 @@ out = sys.argv[1]
 
 
 def load(sub, counter):
-    f = glob.glob(f"{out}/{sub}/*/*_counter_collection.csv")[0]
+    import os
+    f = max(glob.glob(f"{out}/{sub}/*/*_counter_collection.csv"), key=os.path.getmtime)   # newest run
     agg = {}
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter:
@@ -23,9 +24,13 @@ def load(sub, counter):
         fams = ["igemm", "igemm_only"] if "conv_igemm_kernel" in n else \
             ["igemm", "wino_only"] if "conv_wino" in n else \
             ["wgrad"] if "conv_wgrad_kernel" in n else []
+        # a Winograd convolution may be two kernel launches (64-tile blocks + the 16-tile tail,
+        # conv_wino_q_kernel): the tail's bytes count, the tail is not a launch of its own -- so
+        # "per launch" stays "per convolution", like bench.py's flops_per_launch
+        is_tail = "conv_wino_q_kernel" in n
         for fam in fams:
             a = agg.setdefault(fam, [0, 0.0])
-            a[0] += 1
+            a[0] += 0 if is_tail else 1
             a[1] += float(r["Counter_Value"])
     return agg
 
