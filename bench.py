@@ -547,8 +547,8 @@ def main():
             "device_us": dev_us, "launches": 1 if pr.persistent else None, "stages": 38,
             "floor_us": round(floor_us, 1), "frac": round(floor_us / max(dev_us, 1e-9), 4),
             "floor": "2.798 GFLOP / 157.3 TFLOP/s + 89.7 MB of weights / 8 TB/s; the launch is "
-                     "bound by 37 dependent grid-wide hand-offs (~4.5 us each: L2-to-CU operand "
-                     "stream of a stage + barrier), not by either"}
+                     f"bound by 37 dependent grid-wide hand-offs ({dev_us / 38:.1f} us per stage: "
+                     "barrier ~2 us + the stage's dependent memory-side round trips), not by either"}
         model.train()
 
         # ---- BASELINE configs[3] on this GPU's share: ResNet-50 variant, 176x400 frames, trunk
