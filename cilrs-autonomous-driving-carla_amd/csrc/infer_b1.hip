@@ -46,6 +46,15 @@ namespace cilrs {
 namespace {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// threadIdx.x behind an opaque move: everything a stage derives from it is recomputed per stage.
+// Without it the compiler hoists a dozen lane-derived index terms of ALL stage kinds out of the
+// stage loop, runs out of registers and reloads five of them from scratch inside every stage -- a
+// memory round trip on each stage's critical path.
+__device__ __forceinline__ int tid_now() {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
 constexpr int kThreads = 1024;
 constexpr int kSU = 8;                       // k-groups per wave (A and B fragment: 16 buffer loads)
 constexpr int kDescInts = (int)(sizeof(B1Stage) / sizeof(int));
@@ -169,7 +178,7 @@ template <int MODE>
 __device__ __forceinline__ void plan_issue_b(const ConvPlan& p, ConvW& cw, const rsrc_t rsW,
                                              const rsrc_t rsP) {
     const rsrc_t rsB = MODE == 1 ? rsW : rsP;
-    const int kq = (threadIdx.x & 63) >> 4;
+    const int kq = (tid_now() & 63) >> 4;
     const int n = RFL(p.nk) * RFL(p.nt), two = RFL(p.nt) == 2;
     const unsigned w0 = (unsigned)RFL(p.w_off), w1 = (unsigned)RFL(p.w_off1);
 #pragma unroll
@@ -200,7 +209,7 @@ __device__ __forceinline__ void plan_bases(ConvPlan& p, const B1Conv* c) {
 // lane words as [word][thread] (conflict-free), wave scalars as [wave][16].
 constexpr int kPlanLaneWords = kSU + 5;
 __device__ __forceinline__ void plan_save(const ConvPlan& p, unsigned* lds_lane, int* lds_wave) {
-    const int tid = threadIdx.x, wave = RFL(tid >> 6);
+    const int tid = tid_now(), wave = RFL(tid >> 6);
 #pragma unroll
     for (int u = 0; u < kSU; ++u) lds_lane[u * kThreads + tid] = p.offA[u];
     lds_lane[(kSU + 0) * kThreads + tid] = p.wrel;
@@ -215,7 +224,7 @@ __device__ __forceinline__ void plan_save(const ConvPlan& p, unsigned* lds_lane,
     }
 }
 __device__ __forceinline__ void plan_load(ConvPlan& p, const unsigned* lds_lane, const int* lds_wave) {
-    const int tid = threadIdx.x, wave = RFL(tid >> 6);
+    const int tid = tid_now(), wave = RFL(tid >> 6);
     const i32x4* w = reinterpret_cast<const i32x4*>(lds_wave + wave * 16);
     const i32x4 w0 = w[0], w1 = w[1], w2 = w[2];
     plan_clear(p);
@@ -250,7 +259,7 @@ template <int MODE>
 __device__ __forceinline__ void plan_conv(ConvPlan& p, ConvW& cw, const B1Stage* st,
                                           const rsrc_t rsW, const rsrc_t rsP, const int nblk,
                                           const bool defer_b) {
-    const int lane = threadIdx.x & 63, wave = RFL(threadIdx.x >> 6);
+    const int lane = tid_now() & 63, wave = RFL(tid_now() >> 6);
     const int r = lane & 15, kq = lane >> 4;
     const i32x4 hd = *reinterpret_cast<const i32x4*>(st);           // type, wpt, nunits0, total
     const int wpt = RFL(hd[1]), nunits0 = RFL(hd[2]), total = RFL(hd[3]);
@@ -369,7 +378,7 @@ struct ConvEpi { f32x4 add0, add1, sc0, sc1, sh0, sh1; };
 // Multiply phase (every wave): activation loads, MFMAs, partial tiles to LDS [wave][nt][16][16].
 __device__ __forceinline__ void exec_conv_main(const ConvPlan& p, const ConvW& cw, ConvEpi& ep,
                                                const rsrc_t rsW, float* red, long long* fine) {
-    const int lane = threadIdx.x & 63, wave = RFL(threadIdx.x >> 6);
+    const int lane = tid_now() & 63, wave = RFL(tid_now() >> 6);
     const int r = lane & 15, kq = lane >> 4;
     ep.add0 = ep.add1 = ep.sh0 = ep.sh1 = f32x4{0.f, 0.f, 0.f, 0.f};
     ep.sc0 = ep.sc1 = f32x4{1.f, 1.f, 1.f, 1.f};
@@ -443,7 +452,7 @@ __device__ __forceinline__ void exec_conv_main(const ConvPlan& p, const ConvW& c
 __device__ __forceinline__ bool exec_conv_epilogue(const ConvPlan& p, const ConvEpi& ep,
                                                    const rsrc_t rsW, const float* red, int* sync,
                                                    long long* fine) {
-    const int lane = threadIdx.x & 63;
+    const int lane = tid_now() & 63;
     const int row = lane >> 2, c4 = (lane & 3) * 4;
     const int nt = RFL(p.nt), wpt = RFL(p.wpt), grp = RFL(p.grp), ksplit = RFL(p.ksplit);
     const int kj = RFL(p.kj), ticket = RFL(p.ticket), relu = RFL(p.relu), relu_post = RFL(p.relu_post);
@@ -503,17 +512,38 @@ __device__ __forceinline__ bool exec_conv_epilogue(const ConvPlan& p, const Conv
 }
 
 // ---- uint8 HWC frame -> normalised NHWC4 (preprocess_image, autonomous_drive.py:897-902) -------
+// The frame usually sits in PINNED HOST memory (zero-copy): every load is a PCIe read, so what
+// counts is the number of transactions.  Each workgroup takes a CONTIGUOUS run of pixels, one wave
+// fetches the run's bytes as coalesced dwords (a few 64-byte requests per workgroup; the first
+// version read three single bytes per pixel with the pixels interleaved across workgroups: 52,800
+// byte-sized host reads, 13 us for the stage), parks them in LDS and the pixel threads pick their
+// three bytes from there.
+// (the run lives in the kernel's 32 KB `red` array; net.hip checks that it fits)
 __device__ __forceinline__ void pre_stage(const B1Stage* st, const B1Launch& a, const rsrc_t rsW,
-                                          const int nblk) {
+                                          const int nblk, unsigned* pre_lds) {
     const int npix = RFL(st->pH) * RFL(st->pW);
     const unsigned dst = (unsigned)RFL(st->dst_off);
+    const int per = (npix + nblk - 1) / nblk;
+    const int p0 = (int)blockIdx.x * per, p1 = min(npix, p0 + per);
+    const int b0 = 3 * p0, b1 = 3 * p1;
+    unsigned char* bytes = reinterpret_cast<unsigned char*>(pre_lds);
+    const int head = (int)((reinterpret_cast<uintptr_t>(a.frame) + (unsigned)b0) & 3);    // bytes before b0 in its dword
+    if (p0 < p1) {
+        // dwords [b0 - head, ...) of the frame; the last one may reach past b1 but never past the
+        // frame's last dword when the frame's end is dword-aligned, else the tail goes byte-wise
+        const unsigned* src = reinterpret_cast<const unsigned*>(a.frame + b0 - head);
+        const int nd = (b1 - b0 + head) >> 2;
+        for (int k = tid_now(); k < nd; k += kThreads) pre_lds[k] = src[k];
+        for (int k = 4 * nd + tid_now(); k < b1 - b0 + head; k += kThreads) bytes[k] = a.frame[b0 - head + k];
+    }
+    __syncthreads();
     bool stored = false;
-    for (int i = threadIdx.x * nblk + blockIdx.x; i < npix; i += kThreads * nblk) {
-        const unsigned char* p = a.frame + (size_t)i * 3;
+    for (int i = p0 + tid_now(); i < p1; i += kThreads) {
+        const int off = 3 * (i - p0) + head;
         f32x4 v;
-        v[0] = ((float)p[0] / 255.0f - a.mean[0]) / a.stdv[0];
-        v[1] = ((float)p[1] / 255.0f - a.mean[1]) / a.stdv[1];
-        v[2] = ((float)p[2] / 255.0f - a.mean[2]) / a.stdv[2];
+        v[0] = ((float)bytes[off + 0] / 255.0f - a.mean[0]) / a.stdv[0];
+        v[1] = ((float)bytes[off + 1] / 255.0f - a.mean[1]) / a.stdv[1];
+        v[2] = ((float)bytes[off + 2] / 255.0f - a.mean[2]) / a.stdv[2];
         v[3] = 0.f;
         st_act(rsW, dst + (unsigned)i * 16u, v);
         stored = true;
@@ -528,7 +558,7 @@ __device__ __forceinline__ void pre_stage(const B1Stage* st, const B1Launch& a, 
 __device__ __forceinline__ void speed_encoder(const B1Stage* st, const B1Launch& a, const rsrc_t rsW,
                                               const rsrc_t rsP, float* s1) {
     const B1Head* h = &st->h;
-    const int tid = threadIdx.x, lane = tid & 63, wave = RFL(tid >> 6);
+    const int tid = tid_now(), lane = tid & 63, wave = RFL(tid >> 6);
     if (tid < 128) {
         const float w0 = ld_const1(rsP, (unsigned)RFL(h->se_w0) + (unsigned)tid * 4u);
         const float b0 = ld_const1(rsP, (unsigned)RFL(h->se_b0) + (unsigned)tid * 4u);
@@ -564,7 +594,7 @@ __device__ __forceinline__ void pool_stage(const B1Stage* st, const rsrc_t rsW, 
     const int cq = C >> 2;
     const int total = Ho * Wo * cq;
     bool stored = false;
-    for (int i = threadIdx.x * nblk + blockIdx.x; i < total; i += kThreads * nblk) {
+    for (int i = tid_now() * nblk + blockIdx.x; i < total; i += kThreads * nblk) {
         const int q = i % cq, p = i / cq;
         const int ow = p % Wo, oh = p / Wo;
         f32x4 v[9];
@@ -604,7 +634,7 @@ __device__ __forceinline__ void pool_stage(const B1Stage* st, const rsrc_t rsW, 
 __device__ __forceinline__ void head_stage(const B1Stage* st, const B1Launch& a, const rsrc_t rsW,
                                            const rsrc_t rsP, float* hx, const int nblk) {
     const B1Head* h = &st->h;
-    const int tid = threadIdx.x, lane = tid & 63, wave = RFL(tid >> 6);
+    const int tid = tid_now(), lane = tid & 63, wave = RFL(tid >> 6);
     const int cmd = RFL(__builtin_bit_cast(int, __builtin_amdgcn_raw_buffer_load_b32(
         rsW, (int)(unsigned)RFL(st->cmd_off), 0, 16)));            // parked by stage 0; -1: out of range
     const int k = cmd < 0 ? 0 : cmd;
@@ -746,7 +776,24 @@ __global__ __launch_bounds__(kThreads) void infer_b1_kernel(const B1Launch a) {
     const int per_shard = nblk >> 3;
     const int first = a.first_stage;
     const bool poller = RFL(tid >> 6) == 0;            // wave 0 (a scalar: no divergent plans)
-    for (int s = first; s < nstages; ++s) {
+    // Stage 0 of a whole-frame launch is the preprocess stage: it runs OUTSIDE the stage loop so that
+    // its code takes no part in the loop's register allocation (inside the loop's switch it cost
+    // the convolution stages 4 more spilled VGPRs and 10 us per frame).
+    int s_begin = first;
+    if (first == 0 && RFL(desc_stage(desc, 0)->type) == B1_PRE) {
+        if (a.stamps && blockIdx.x == 0 && tid == 0) a.stamps[0] = __builtin_amdgcn_s_memrealtime();
+        pre_stage(desc_stage(desc, 0), a, rsW, nblk, reinterpret_cast<unsigned*>(red));
+        if (a.stamps && blockIdx.x == 0 && tid == 0)
+            a.stamps[kB1MaxStages + 1] = __builtin_amdgcn_s_memrealtime();
+        if (a.stamps && tid == 0)
+            a.stamps[10 * (kB1MaxStages + 1) + blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+        if (1 < nstages) {
+            grid_arrive(a.sync);
+            if ((int)blockIdx.x == nblk - 1) speed_encoder(desc_stage(desc, 0), a, rsW, rsP, s1);
+        }
+        s_begin = 1;
+    }
+    for (int s = s_begin; s < nstages; ++s) {
         const B1Stage* st = desc_stage(desc, s);
         const int type = RFL(st->type);
         int failed = RFL(*reinterpret_cast<volatile int*>(&fail));     // wave-uniform
@@ -790,7 +837,6 @@ __global__ __launch_bounds__(kThreads) void infer_b1_kernel(const B1Launch a) {
             }
         } else if (!failed) {
             if (type == B1_POOL) pool_stage(st, rsW, nblk);
-            else if (type == B1_PRE) pre_stage(st, a, rsW, nblk);
             else head_stage(st, a, rsW, rsP, hx, nblk);     // (these drain their own stores)
         }
         if (a.stamps && blockIdx.x == 0 && tid == 0)

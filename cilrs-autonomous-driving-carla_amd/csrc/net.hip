@@ -1619,6 +1619,9 @@ static int b1_build(cilrs_net* net, int nblk) {
         B1Stage st;
         memset(&st, 0, sizeof(st));
         st.type = B1_PRE; st.pH = net->H; st.pW = net->W; st.dst_off = fb(net->x4);
+        // (a workgroup parks its run of the frame's bytes in 32 KB of LDS: infer_b1.hip pre_stage)
+        CILRS_CHECK(3 * cdiv(net->H * net->W, nblk) + 8 <= 16 * 512 * 4,
+                    "persistent kernel: frame too large for %d workgroups", nblk);
         // ... and the speed encoder, evaluated by one block beside the pixel work
         st.h.se_w0 = fb(A.se0.w); st.h.se_b0 = fb(A.se0.b);
         st.h.se_w1 = fb(A.se3.w); st.h.se_b1 = fb(A.se3.b);
