@@ -1685,8 +1685,9 @@ def _env_step(env_extra, B):
 
 def test_library_switches_keep_the_step(tmp_path):
     """The process-wide switches that select another kernel for the same arithmetic -- CILRS_WINO=0
-    (implicit GEMM instead of Winograd on layers 1-3) and CILRS_BN_FUSED=1 (BatchNorm finalize
-    inside the apply launch, the measured-slower variant of profiles/r03_bn_fused.log) -- are read
+    (implicit GEMM instead of Winograd on layers 1-3), CILRS_BN_FUSED=1 (BatchNorm finalize
+    inside the apply launch, the measured-slower variant of profiles/r03_bn_fused.log),
+    CILRS_OVERLAP=0 and CILRS_WINO_TAIL=0 (which Winograd launches get a 16-tile tail) -- are read
     once per process, so each runs two B=128 train steps in a child process.  The loss of the second
     step and the BatchNorm running-statistic checksums must agree with the default kernels to fp32
     rounding (the kernels differ in summation order, not in what they compute); the parameter
@@ -1695,7 +1696,10 @@ def test_library_switches_keep_the_step(tmp_path):
     Adam's lr * sign-like update is decided by a gradient inside fp32 noise of zero)."""
     base = _env_step({}, 128)
     assert base["wino"] == 24
-    for env in ({"CILRS_WINO": "0"}, {"CILRS_BN_FUSED": "1"}):
+    # CILRS_OVERLAP=0: no side stream -- the data gradients then take the 16-tile Winograd tail launch
+    # too (with its BatchNorm-backward partials); CILRS_WINO_TAIL=0: no tail launches at all
+    for env in ({"CILRS_WINO": "0"}, {"CILRS_BN_FUSED": "1"}, {"CILRS_OVERLAP": "0"},
+                {"CILRS_WINO_TAIL": "0"}):
         got = _env_step(env, 128)
         assert got["wino"] == (0 if "CILRS_WINO" in env else 24)
         assert abs(got["loss"] - base["loss"]) <= 2e-4 * max(1.0, abs(base["loss"])), (env, got, base)
