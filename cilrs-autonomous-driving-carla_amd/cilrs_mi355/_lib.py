@@ -111,6 +111,8 @@ SIGNATURES = {
     "cilrs_conv2d_wino_stamps": (i32, [vp]),
     "cilrs_conv2d_wino_pre": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "cilrs_conv2d_wino_dgrad": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
+    "cilrs_conv2d_wino_wgrad_scratch_floats": (sz, [i32, i32, i32, i32, i32]),
+    "cilrs_conv2d_wino_wgrad": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp, sz, vp]),
     "cilrs_bn_partial_floats": (sz, [i32]),
     "cilrs_bn_train_fwd": (i32, [vp, i32, i32, vp, vp, vp, vp, vp, f32, f32, vp, i32, vp, vp, vp,
                                  vp]),

@@ -317,6 +317,26 @@ int wino_groups(int N, int H, int W);        // 64-tile groups of a launch
 // column-partial rows launch_conv_wino writes for these sizes (full groups + 16-tile tail groups)
 int wino_rows(int N, int H, int W, int K, int no_tail = 0);
 int launch_conv_wino(const WinoArgs& a, hipStream_t s);
+// Weight gradient of the same convolutions in the Winograd domain:
+//   dU_xi[k][c] = sum over tiles of (A dY A^T)_xi[tile][k] * (B^T d B)_xi[tile][c],  dw = G^T dU G
+// (16 products per tile, channel pair and tap set instead of 36).  The tile range is split over
+// `splits` blocks per 64 x 64 channel tile (chosen so that one round fills the chip); each block
+// writes an OHWI slab, summed in slab order by launch_wgrad_reduce.
+struct WinoWgradArgs {
+    const float* x;          // [N][H][W][C] input activations of the convolution
+    const float* dy;         // [N][H][W][K] output gradient
+    float* dw;               // [K][3][3][C]
+    float* slabs;            // wino_wgrad_scratch_floats floats
+    int N, H, W, C, K;
+    int accumulate;
+    // filled in by the launcher:
+    int splits, tiles_per_split;
+};
+bool wino_wgrad_supported(int C, int K, int ksize, int stride, int pad);
+size_t wino_wgrad_scratch_floats(int N, int H, int W, int C, int K);
+int launch_conv_wino_wgrad(const WinoWgradArgs& a, hipStream_t s);
+int launch_wgrad_reduce(const float* slabs, float* dw, int splits, size_t n, int accumulate,
+                        hipStream_t s);
 int wino_prepare();                          // one-time kernel attribute (call outside stream capture)
 // Both filter forms of every Winograd convolution of a network in ONE launch (the weights change
 // every optimiser step): block = 8 output x 32 input channels of one layer, staged through LDS so

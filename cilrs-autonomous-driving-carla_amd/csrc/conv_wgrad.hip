@@ -483,4 +483,20 @@ int launch_conv_wgrad(const WgradArgs& a_in, hipStream_t s) {
     return 0;
 }
 
+// slabs[splits][n] -> dw[n] in slab order (n % 4 == 0, 16-byte aligned): the reduce of
+// launch_conv_wgrad on its own, for the Winograd weight gradient (conv_wino.hip)
+int launch_wgrad_reduce(const float* slabs, float* dw, int splits, size_t n, int accumulate,
+                        hipStream_t s) {
+    CILRS_CHECK(n % 4 == 0 && ((uintptr_t)dw & 15) == 0 && ((uintptr_t)slabs & 15) == 0,
+                "wgrad_reduce: n %% 4, 16-byte aligned buffers");
+    const size_t nvec = n / 4;
+    int G = 1;
+    while (G < 16 && nvec * G < 131072 && 8 * G <= splits) G *= 2;
+    const int opb = 256 / G;
+    wgrad_reduce_kernel<4><<<(int)((nvec + opb - 1) / opb), 256, 0, s>>>(slabs, dw, splits, n, 0, 0,
+                                                                        accumulate, G);
+    CILRS_LAUNCH_CHECK();
+    return 0;
+}
+
 }  // namespace cilrs

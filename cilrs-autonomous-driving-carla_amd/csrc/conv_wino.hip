@@ -728,6 +728,214 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_q_kernel(const WinoArgs a)
     }
 }
 
+// ---- weight gradient in the Winograd domain ---------------------------------------------------------
+// Block = 512 threads: 64 output x 64 input channels x all 16 positions, reduction over a run of
+// tiles in chunks of 8.  Wave w owns 16 output channels (w & 3) x 32 input channels (w >> 2) for
+// all 16 positions (128 accumulator registers, rows = output channels): the inverse transform
+// G^T dU G is register-local, the result goes to an OHWI slab with 64-byte runs.  Producers: waves
+// 0-3 gather the 4x4 input patches of the chunk's 8 tiles (thread = tile x channel pair: 256
+// contiguous bytes per patch pixel) and build V = B^T d B, waves 4-7 the 2x2 output-gradient
+// pixels and P = A dY A^T; both land in LDS as [position][tile][64 channels + 8 pad] -- channel
+// fastest, so the stores are 256-byte runs, and the operand fragment of a lane (one channel, two
+// consecutive tiles) is ONE ds_read2_b32 on conflict-free banks (row pitch 72).  Same two-phase
+// loop as the forward kernel.  Unlike the forward pass the split of the reduction is free, so one
+// round fills the chip (no 2.15-rounds-pay-3).
+constexpr int GT = 8;                        // tiles per chunk
+constexpr int GP = 72;                       // LDS row pitch (floats)
+constexpr int GOP = 16 * GT * GP;            // floats per operand image (36,864 B)
+constexpr int GSTAGE = 2 * GOP;
+constexpr size_t kWinoGLds = (size_t)2 * GSTAGE * sizeof(float);       // 147,456 B
+__global__ __launch_bounds__(WTHREADS) void wino_wgrad_kernel(const WinoWgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int kg = wave & 3, cg = wave >> 2;
+    const int TH = (a.H + 1) >> 1, TW = (a.W + 1) >> 1;
+    const int tiles_img = TH * TW, total_tiles = a.N * tiles_img;
+    const int nct = a.C / 64, nkt = a.K / 64;
+    const int ct = blockIdx.x % nct, kt = (blockIdx.x / nct) % nkt, sp = blockIdx.x / (nct * nkt);
+    const int c0 = ct * 64, k0 = kt * 64;
+    const int t0 = sp * a.tiles_per_split;
+    const int t1 = min(total_tiles, t0 + a.tiles_per_split);
+    const int nchunks = t1 > t0 ? (t1 - t0 + GT - 1) / GT : 0;
+
+    // ---- producer roles: thread = (tile j of the chunk, channel pair p) ----
+    const bool vprod = tid < 256;                         // waves 0-3: V;  waves 4-7: P
+    const int pj = (tid >> 5) & 7, pp = tid & 31;
+    // this thread's tile of chunk 0, then + 8 tiles per chunk (incremental: no division in the loop)
+    int tn, tty, ttx, tcur = t0 + pj;
+    {
+        const int t = min(tcur, total_tiles - 1);
+        tn = t / tiles_img;
+        const int rem = t - tn * tiles_img;
+        tty = rem / TW;
+        ttx = rem - tty * TW;
+    }
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.x, 0, (int)(unsigned)((size_t)a.N * a.H * a.W * a.C * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.dy, 0, (int)(unsigned)((size_t)a.N * a.H * a.W * a.K * 4), 0x00020000);
+    f32x2 d[16];                    // V producers: the 4x4 patch;  P producers: d[0..3] = the 2x2 pixels
+    auto load_chunk = [&]() {       // the thread's current tile (tn, tty, ttx), valid if tcur < t1
+        const bool tv = tcur < t1;
+        if (vprod) {
+            const int h0 = 2 * tty - 1, w0 = 2 * ttx - 1;
+            const int base = (((tn * a.H + h0) * a.W + w0) * a.C + c0 + 2 * pp) * 4;
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                const int h = h0 + (p >> 2), w = w0 + (p & 3);
+                const bool ok = tv && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W;
+                const unsigned off = ok ? (unsigned)(base + ((p >> 2) * a.W + (p & 3)) * a.C * 4) : 0xFFFFFFFFu;
+                d[p] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsX, (int)off, 0, 0));
+            }
+        } else {
+            const int h0 = 2 * tty, w0 = 2 * ttx;
+            const int base = (((tn * a.H + h0) * a.W + w0) * a.K + k0 + 2 * pp) * 4;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int h = h0 + (p >> 1), w = w0 + (p & 1);
+                const bool ok = tv && h < a.H && w < a.W;
+                const unsigned off = ok ? (unsigned)(base + ((p >> 1) * a.W + (p & 1)) * a.K * 4) : 0xFFFFFFFFu;
+                d[p] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsD, (int)off, 0, 0));
+            }
+        }
+        // next chunk's tile
+        tcur += GT;
+        ttx += GT;
+        while (ttx >= TW) { ttx -= TW; ++tty; }
+        while (tty >= TH) { tty -= TH; ++tn; }
+    };
+    auto store_chunk = [&](const int stage) {
+        float* img = smem + stage * GSTAGE + (vprod ? 0 : GOP) + pj * GP + pp * 2;
+        if (vprod) {
+            // V = B^T d B;  B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x2 r0 = d[0 * 4 + j] - d[2 * 4 + j];
+                const f32x2 r1 = d[1 * 4 + j] + d[2 * 4 + j];
+                const f32x2 r2 = d[2 * 4 + j] - d[1 * 4 + j];
+                const f32x2 r3 = d[1 * 4 + j] - d[3 * 4 + j];
+                d[0 * 4 + j] = r0; d[1 * 4 + j] = r1; d[2 * 4 + j] = r2; d[3 * 4 + j] = r3;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x2 v0 = d[i * 4 + 0] - d[i * 4 + 2];
+                const f32x2 v1 = d[i * 4 + 1] + d[i * 4 + 2];
+                const f32x2 v2 = d[i * 4 + 2] - d[i * 4 + 1];
+                const f32x2 v3 = d[i * 4 + 1] - d[i * 4 + 3];
+                *reinterpret_cast<f32x2*>(img + (i * 4 + 0) * (GT * GP)) = v0;
+                *reinterpret_cast<f32x2*>(img + (i * 4 + 1) * (GT * GP)) = v1;
+                *reinterpret_cast<f32x2*>(img + (i * 4 + 2) * (GT * GP)) = v2;
+                *reinterpret_cast<f32x2*>(img + (i * 4 + 3) * (GT * GP)) = v3;
+            }
+        } else {
+            // P = A dY A^T;  A = [[1,0],[1,1],[1,-1],[0,-1]];  d[0..3] = dY[0][0], [0][1], [1][0], [1][1]
+            f32x2 r[4][2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                r[0][b] = d[b];
+                r[1][b] = d[b] + d[2 + b];
+                r[2][b] = d[b] - d[2 + b];
+                r[3][b] = -d[2 + b];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                *reinterpret_cast<f32x2*>(img + (i * 4 + 0) * (GT * GP)) = r[i][0];
+                *reinterpret_cast<f32x2*>(img + (i * 4 + 1) * (GT * GP)) = r[i][0] + r[i][1];
+                *reinterpret_cast<f32x2*>(img + (i * 4 + 2) * (GT * GP)) = r[i][0] - r[i][1];
+                *reinterpret_cast<f32x2*>(img + (i * 4 + 3) * (GT * GP)) = -r[i][1];
+            }
+        }
+    };
+
+    f32x4 acc[16][2];
+#pragma unroll
+    for (int x = 0; x < 16; ++x)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) acc[x][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // operand fragments: MFMA k index lq = tiles 2 lq, 2 lq + 1 of the chunk (the two k-steps)
+    const int frag_p = GOP + (2 * lq) * GP + kg * 16 + l15;        // rows: output channels
+    const int frag_v = (2 * lq) * GP + cg * 32 + l15;              // columns: input channels
+    auto multiply = [&](const int ch) {
+        const float* Pc = smem + (ch & 1) * GSTAGE + frag_p;
+        const float* Vc = smem + (ch & 1) * GSTAGE + frag_v;
+        constexpr int D = 2;
+        f32x2 pa[D + 1], v0[D + 1], v1[D + 1];
+        auto rd = [&](const int x, const int slot) {
+            pa[slot] = f32x2{Pc[x * (GT * GP)], Pc[x * (GT * GP) + GP]};
+            v0[slot] = f32x2{Vc[x * (GT * GP)], Vc[x * (GT * GP) + GP]};
+            v1[slot] = f32x2{Vc[x * (GT * GP) + 16], Vc[x * (GT * GP) + GP + 16]};
+        };
+#pragma unroll
+        for (int x = 0; x < D; ++x) rd(x, x);
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) {
+            const int cur = xi % (D + 1), nxt = (xi + D) % (D + 1);
+            if (xi + D < 16) rd(xi + D, nxt);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[cur][s], v0[cur][s], acc[xi][0], 0, 0, 0);
+                acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[cur][s], v1[cur][s], acc[xi][1], 0, 0, 0);
+            }
+            if (xi + D < 16) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        }
+    };
+
+    if (nchunks > 0) {
+        load_chunk();
+        store_chunk(0);
+        if (nchunks > 1) load_chunk();
+    }
+    __syncthreads();
+    const bool late = wave >= 4;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        if (late) {
+            if (ch + 1 < nchunks) { store_chunk((ch + 1) & 1); if (ch + 2 < nchunks) load_chunk(); }
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            multiply(ch);
+        } else {
+            multiply(ch);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            if (ch + 1 < nchunks) { store_chunk((ch + 1) & 1); if (ch + 2 < nchunks) load_chunk(); }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: dw = G^T dU G per (k, c), register-local;  G^T = [[1,.5,.5,0],[0,.5,-.5,0],[0,.5,.5,1]] ----
+    float* slab = a.slabs + (size_t)sp * a.K * 9 * a.C;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        f32x4 t[3][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 hs = 0.5f * (acc[1 * 4 + q][m] + acc[2 * 4 + q][m]);
+            t[0][q] = acc[0 * 4 + q][m] + hs;
+            t[1][q] = 0.5f * (acc[1 * 4 + q][m] - acc[2 * 4 + q][m]);
+            t[2][q] = hs + acc[3 * 4 + q][m];
+        }
+        const int c = c0 + cg * 32 + m * 16 + l15;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const f32x4 hs = 0.5f * (t[p][1] + t[p][2]);
+            const f32x4 g0 = t[p][0] + hs;
+            const f32x4 g1 = 0.5f * (t[p][1] - t[p][2]);
+            const f32x4 g2 = hs + t[p][3];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = k0 + kg * 16 + lq * 4 + r;
+                float* dst = slab + ((size_t)k * 9 + p * 3) * a.C + c;
+                dst[0] = g0[r];
+                dst[a.C] = g1[r];
+                dst[2 * a.C] = g2[r];
+            }
+        }
+    }
+}
+
 }  // namespace
 
 size_t wino_weight_floats(int K, int C) { return (size_t)16 * K * C; }
@@ -823,6 +1031,50 @@ int launch_conv_wino(const WinoArgs& a_in, hipStream_t s) {
         CILRS_LAUNCH_CHECK();
     }
     return 0;
+}
+
+bool wino_wgrad_supported(int C, int K, int ksize, int stride, int pad) {
+    return ksize == 3 && stride == 1 && pad == 1 && C % 64 == 0 && K % 64 == 0;
+}
+static void wino_wgrad_split(int N, int H, int W, int C, int K, int* splits, int* tps) {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess &&
+               p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+    }
+    const int tiles = N * ((H + 1) / 2) * ((W + 1) / 2);
+    const int kc = (C / 64) * (K / 64);
+    int s = cus / kc;
+    if (s < 1) s = 1;
+    int per = cdiv(cdiv(tiles, s), GT) * GT;          // whole chunks
+    if (per < GT) per = GT;
+    *tps = per;
+    *splits = cdiv(tiles, per);
+}
+size_t wino_wgrad_scratch_floats(int N, int H, int W, int C, int K) {
+    int splits, tps;
+    wino_wgrad_split(N, H, W, C, K, &splits, &tps);
+    return (size_t)splits * K * 9 * C;
+}
+int launch_conv_wino_wgrad(const WinoWgradArgs& a_in, hipStream_t s) {
+    WinoWgradArgs a = a_in;
+    CILRS_CHECK(a.x && a.dy && a.dw && a.slabs, "conv_wino_wgrad: NULL tensor");
+    CILRS_CHECK(a.C % 64 == 0 && a.K % 64 == 0, "conv_wino_wgrad: C %% 64, K %% 64");
+    CILRS_CHECK((size_t)a.N * a.H * a.W * a.C * 4 < (1ull << 31) &&
+                    (size_t)a.N * a.H * a.W * a.K * 4 < (1ull << 31),
+                "conv_wino_wgrad: tensor too large for 32-bit offsets");
+    static bool attr_set = false;
+    if (!attr_set) {
+        CILRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_wgrad_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoGLds));
+        attr_set = true;
+    }
+    wino_wgrad_split(a.N, a.H, a.W, a.C, a.K, &a.splits, &a.tiles_per_split);
+    wino_wgrad_kernel<<<a.splits * (a.C / 64) * (a.K / 64), WTHREADS, kWinoGLds, s>>>(a);
+    CILRS_LAUNCH_CHECK();
+    return launch_wgrad_reduce(a.slabs, a.dw, a.splits, (size_t)a.K * 9 * a.C, a.accumulate, s);
 }
 
 }  // namespace cilrs

@@ -389,6 +389,13 @@ int cilrs_conv2d_wino_pre(const float* x, const float* U, float* y, const float*
                           int W, int Cred, int Cout, void* stream);
 int cilrs_conv2d_wino_dgrad(const float* dy, const float* w, float* dx, const float* addend, int N,
                             int H, int W, int Cin, int Cout, float* scratch, void* stream);
+/* Weight gradient of the same convolution in the Winograd domain (cuDNN conv bwd-filter, i.e. the
+ * `loss.backward()` of notebook/notebook.ipynb:551 for a 3x3 / stride-1 layer): dw[Cout][3][3][Cin]
+ * from x[N][H][W][Cin] and dy[N][H][W][Cout]; Cin % 64 == 0, Cout % 64 == 0.  scratch:
+ * cilrs_conv2d_wino_wgrad_scratch_floats floats (per-split slabs, summed in fixed order). */
+size_t cilrs_conv2d_wino_wgrad_scratch_floats(int N, int H, int W, int Cin, int Cout);
+int cilrs_conv2d_wino_wgrad(const float* x, const float* dy, float* dw, int N, int H, int W, int Cin,
+                            int Cout, float* scratch, size_t scratch_floats, void* stream);
 size_t cilrs_bn_partial_floats(int C);
 int cilrs_bn_train_fwd(const float* y, int M, int C, const float* gamma, const float* beta,
                        float* running_mean, float* running_var, int64_t* nbt, float momentum,

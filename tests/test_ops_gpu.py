@@ -642,3 +642,20 @@ def test_conv_wino_fwd_and_dgrad(case):
         want = x.grad + add
         assert torch.isfinite(gdx).all()
         assert float((gdx - want).abs().max()) <= _tol(want, 5e-5)
+        # weight gradient in the Winograd domain against a float64 computation of the same sum:
+        # error <= 2x torch-fp32's own (the reduction is N x H x W long: up to 140,800 terms)
+        x64, w64 = x.detach().double().requires_grad_(False), w.double().requires_grad_(True)
+        F.conv2d(x64, w64, None, 1, 1).backward(dy.double())
+        w32 = w.clone().requires_grad_(True)
+        F.conv2d(x.detach(), w32, None, 1, 1).backward(dy)
+        nsc = lib.cilrs_conv2d_wino_wgrad_scratch_floats(N, H, W, Cin, Cout)
+        sc2 = torch.empty(nsc, device="cuda")
+        dw = torch.full((Cout, 3, 3, Cin), float("nan"), device="cuda")
+        L.check(lib.cilrs_conv2d_wino_wgrad(L.ptr(xd), L.ptr(dyd), L.ptr(dw), N, H, W, Cin, Cout,
+                                            L.ptr(sc2), nsc, stream()))
+        torch.cuda.synchronize()
+        gdw = dw.cpu().permute(0, 3, 1, 2).double()
+        assert torch.isfinite(gdw).all()
+        e_hip = float((gdw - w64.grad).abs().max())
+        e_cpu = float((w32.grad.double() - w64.grad).abs().max())
+        assert e_hip <= max(2.0 * e_cpu, 2e-5 * float(w64.grad.abs().max())), (e_hip, e_cpu)

@@ -68,3 +68,25 @@ for name, H, W, Cc in (("layer1", 22, 50, 64), ("layer2", 11, 25, 128), ("layer3
           f"({fl / t_p / 1e6:.1f} TF effective)")
     print(f"{name} N={N} {H}x{W}x{Cc}: implicit GEMM {t_i:7.1f} us ({fl / t_i / 1e6:6.1f} TF)   "
           f"Winograd incl. filter transform {t_w:7.1f} us ({fl / t_w / 1e6:6.1f} TF effective)   x{t_i / t_w:.2f}")
+
+# ---- weight gradient: direct kernel (its own split plan + slab reduce) against the Winograd-domain one
+print("weight gradient (incl. the slab reduce):")
+for name, H, W, Cc in (("layer1", 22, 50, 64), ("layer2", 11, 25, 128), ("layer3", 6, 13, 256),
+                       ("layer4", 3, 7, 512)):
+    x = torch.randn(N, H, W, Cc, device="cuda")
+    dy = torch.randn(N, H, W, Cc, device="cuda")
+    dw = torch.empty(Cc, 3, 3, Cc, device="cuda")
+    n_d = lib.cilrs_conv2d_wgrad_scratch_floats(N, H, W, Cc, Cc, 3, 3, 1, 1)
+    n_w = lib.cilrs_conv2d_wino_wgrad_scratch_floats(N, H, W, Cc, Cc)
+    sc = torch.empty(max(n_d, n_w, 4), device="cuda")
+    fl = 2.0 * N * H * W * Cc * 9 * Cc
+
+    def direct():
+        L.check(lib.cilrs_conv2d_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dw), L.ptr(sc), N, H, W, Cc, Cc, 3, 3, 1, 1,
+                                       Cc, st))
+
+    def wino_w():
+        L.check(lib.cilrs_conv2d_wino_wgrad(L.ptr(x), L.ptr(dy), L.ptr(dw), N, H, W, Cc, Cc, L.ptr(sc), sc.numel(), st))
+    t_d, t_w = timed(direct), timed(wino_w)
+    print(f"{name} N={N} {H}x{W}x{Cc}: direct {t_d:7.1f} us ({fl / t_d / 1e6:6.1f} TF)   Winograd {t_w:7.1f} us "
+          f"({fl / t_w / 1e6:6.1f} TF effective, {n_w * 4 / 1e6:.1f} MB of slabs)   x{t_d / t_w:.2f}")
