@@ -23,7 +23,8 @@ def load(sub, counter):
         # are also listed on their own
         fams = ["igemm", "igemm_only"] if "conv_igemm_kernel" in n else \
             ["igemm", "wino_only"] if "conv_wino" in n else \
-            ["wgrad"] if "conv_wgrad_kernel" in n else []
+            ["wgrad", "wgrad_direct_only"] if "conv_wgrad_kernel" in n else \
+            ["wgrad", "wgrad_wino_only"] if "wino_wgrad_kernel" in n else []
         # a Winograd convolution may be two kernel launches (64-tile blocks + the 16-tile tail,
         # conv_wino_q_kernel): the tail's bytes count, the tail is not a launch of its own -- so
         # "per launch" stays "per convolution", like bench.py's flops_per_launch
