@@ -109,7 +109,7 @@ class Plan:
             raise RuntimeError("CILRS persistent forward: a grid barrier gave up (another "
                                "persistent launch was holding the device); outputs are NaN")
         if st[0] != 0:
-            raise RuntimeError("CILRS.forward: command index out of range (expected 0..3); "
+            raise RuntimeError("CILRS.forward: command index out of range (expected 0..num_commands-1); "
                                "torch.gather raises 'index out of bounds' here "
                                "(model/autonomous_drive.py:397-398)")
 

@@ -94,10 +94,11 @@ class CILRS(nn.Module):
 
     def __init__(self, num_commands=4, dropout=0.0):
         super().__init__()
-        if num_commands != 4:
-            # the reference's ctor is generic (autonomous_drive.py:362, 380-381) but every caller
-            # passes 4 and the kernels' arena layout is fixed ("Differences")
-            raise ValueError("the HIP engine implements the reference's 4 command branches")
+        # generic like the reference's ctor (autonomous_drive.py:362, 380-381); every caller of the
+        # reference passes 4.  The engine lays its arena out per plan for 1..8 branches; the
+        # single-launch persistent frame kernel and the evaluation report exist for 4 only.
+        if not (isinstance(num_commands, int) and 1 <= num_commands <= 8):
+            raise ValueError("num_commands must be an integer in 1..8")
         self.num_commands = num_commands
         self.dropout = float(dropout)
         self.visual_encoder = self._trunk()
@@ -150,7 +151,9 @@ class CILRS(nn.Module):
         """The HIP engine bound to this module's parameters (built on first use)."""
         eng = self._engine
         if eng is None or not eng.is_attached():
-            eng = Engine(self, self.VARIANT)
+            # architecture code of the C-ABI: trunk | num_commands << 8 (0 = the reference's 4)
+            code = self.VARIANT | ((self.num_commands << 8) if self.num_commands != 4 else 0)
+            eng = Engine(self, code)
             self._engine = eng
             _track(self)
         return eng

@@ -91,14 +91,14 @@ class Predictor:
             self.stream.wait_stream(torch.cuda.current_stream(self.eng.device))
             self._seen_epoch = self.eng.weights_epoch
 
-    @staticmethod
-    def _check_commands(commands):
+    def _check_commands(self, commands):
         # the command comes from the host (route planner, autonomous_drive.py:1589-1593): validate
-        # it here -- a value outside 0..3 raises exactly where the reference's torch.gather does
+        # it here -- a value outside 0..num_commands-1 raises exactly where the reference's torch.gather does
         # (:397-398, :915-917), without waiting for the device's status word
         c = np.asarray(commands, dtype=np.int64)
-        if c.size and (c.min() < 0 or c.max() > 3):
-            raise RuntimeError("predict_controls: command index out of range (expected 0..3)")
+        nc = getattr(self.model, "num_commands", 4)
+        if c.size and (c.min() < 0 or c.max() >= nc):
+            raise RuntimeError(f"predict_controls: command index out of range (expected 0..{nc - 1})")
         return c
 
     @torch.no_grad()

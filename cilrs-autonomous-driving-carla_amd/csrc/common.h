@@ -248,8 +248,12 @@ int launch_colsum(const float* dy, float* db, int B, int out, int dy_ld, int acc
                   hipStream_t s);
 int launch_relu_mask(float* d, const float* act, int B, int cols, int d_ld, int act_ld,
                      float scale, hipStream_t s);
-int launch_sum_parts(const float* p0, const float* p1, const float* p2, const float* p3,
-                     const float* p4, float* out, int B, int cols, int cols4, hipStream_t s);
+// The reference builds one control branch per command (autonomous_drive.py:362, 380-381); every
+// caller passes 4.  Plans are generic up to kMaxCmd branches (a plan parameter, encoded in the
+// variant code: trunk | num_commands << 8, 0 meaning 4).
+constexpr int kMaxCmd = 8;
+struct SumParts { const float* p[kMaxCmd]; int n; const float* tail; };   // n branch parts + the speed head's
+int launch_sum_parts(const SumParts& parts, float* out, int B, int cols, int cols_tail, hipStream_t s);
 int launch_dropout(float* a, int B, int cols, int ld, float p, unsigned long long seed,
                    unsigned long long stream, hipStream_t s);
 // small-batch inference heads (eval, B <= kHeadsSmallMaxB): only the commanded branch of each
@@ -258,15 +262,16 @@ int launch_dropout(float* a, int B, int cols, int ld, float p, unsigned long lon
 constexpr int kHeadsSmallMaxB = 16;
 struct HeadsSmallArgs {
     const float* x[2];       // input rows per chain, leading dimension x_ld
-    const float* w[5];       // branch 0..3 weights [out][in], then the speed-head layer
-    const float* b[5];
+    const float* w[kMaxCmd + 1];   // branch 0..ncmd-1 weights [out][in], then (index ncmd) the speed-head layer
+    const float* b[kMaxCmd + 1];
+    int ncmd;
     float* y[2];
     int y_ld[2];
     int out[2];
     int in[2];               // input features per chain
     int x_ld, relu, B;
     const long long* cmd;    // [B] command per row
-    int* status;             // set to 1 on a command outside 0..3 (may be NULL)
+    int* status;             // set to 1 on a command outside 0..ncmd-1 (may be NULL)
 };
 int launch_heads_small_pre(const float* feat, int HW, const float* speed, const float* w0,
                            const float* b0, const float* w1, const float* b1, float* combined,
@@ -504,7 +509,7 @@ struct HGemmGroup {
     int vec;                           // set by the launcher
 };
 struct HGemmArgs {
-    HGemmGroup g[5];
+    HGemmGroup g[kMaxCmd + 1];
     int ngroups, relu, accumulate;
     float drop_p;
     unsigned long long seed;

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void hgemm_kernel(const HGemmArgs a) {
 }  // namespace
 
 int launch_hgemm(int mode, HGemmArgs& a, hipStream_t s) {
-    CILRS_CHECK(a.ngroups >= 1 && a.ngroups <= 5, "hgemm: 1..5 groups");
+    CILRS_CHECK(a.ngroups >= 1 && a.ngroups <= kMaxCmd + 1, "hgemm: 1..%d groups", kMaxCmd + 1);
     int maxM = 0, maxN = 0;
     for (int i = 0; i < a.ngroups; ++i) {
         HGemmGroup& g = a.g[i];

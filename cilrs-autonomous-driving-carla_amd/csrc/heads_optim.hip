@@ -249,19 +249,16 @@ __global__ __launch_bounds__(256) void relu_mask_kernel(float* __restrict__ d,
     d[o] = act[(size_t)b * act_ld + c] > 0.f ? d[o] * scale : 0.f;
 }
 
-// out[b][c] = p0+p1+p2+p3 (+ p4 for c < cols4) -- fixed order, deterministic
-__global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict__ p0,
-                                                        const float* __restrict__ p1,
-                                                        const float* __restrict__ p2,
-                                                        const float* __restrict__ p3,
-                                                        const float* __restrict__ p4,
-                                                        float* __restrict__ out, const int B,
-                                                        const int cols, const int cols4) {
+// out[b][c] = ((p0+p1)+p2)+... (+ tail for c < cols_tail) -- fixed order, deterministic
+__global__ __launch_bounds__(256) void sum_parts_kernel(const SumParts parts, float* __restrict__ out,
+                                                        const int B, const int cols,
+                                                        const int cols_tail) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * cols) return;
     const int c = i % cols;
-    float v = ((p0[i] + p1[i]) + p2[i]) + p3[i];
-    if (c < cols4) v += p4[i];
+    float v = parts.p[0][i];
+    for (int k = 1; k < parts.n; ++k) v += parts.p[k][i];
+    if (c < cols_tail) v += parts.tail[i];
     out[i] = v;
 }
 
@@ -332,14 +329,14 @@ __global__ __launch_bounds__(256) void heads_small_layer_kernel(const HeadsSmall
     const float* xbase = a.x[chain];
     float* ybase = a.y[chain];
     const int y_ld = a.y_ld[chain];
-    const int nk = chain ? 1 : 4;
+    const int nk = chain ? 1 : a.ncmd;
     for (int k = 0; k < nk; ++k) {
-        const int widx = chain ? 4 : k;
+        const int widx = chain ? a.ncmd : k;
         if (!chain) {
             bool any = false;
             for (int b = 0; b < a.B; ++b) {
                 const long long c = a.cmd[b];
-                any |= ((c < 0 || c > 3) ? 0 : (int)c) == k;
+                any |= ((c < 0 || c >= a.ncmd) ? 0 : (int)c) == k;
             }
             if (!any) continue;
         }
@@ -354,7 +351,7 @@ __global__ __launch_bounds__(256) void heads_small_layer_kernel(const HeadsSmall
         for (int b = 0; b < a.B; ++b) {
             if (!chain) {
                 const long long c = a.cmd[b];
-                if (((c < 0 || c > 3) ? 0 : (int)c) != k) continue;
+                if (((c < 0 || c >= a.ncmd) ? 0 : (int)c) != k) continue;
             }
             const float* xr = xbase + (size_t)b * a.x_ld;
             float acc = 0.f;
@@ -380,7 +377,7 @@ __global__ __launch_bounds__(256) void heads_small_layer_kernel(const HeadsSmall
     }
     if (a.status && !chain && o == 0 && lane == 0) {   // torch.gather would raise
         for (int b = 0; b < a.B; ++b)
-            if (a.cmd[b] < 0 || a.cmd[b] > 3) *a.status = 1;
+            if (a.cmd[b] < 0 || a.cmd[b] >= a.ncmd) *a.status = 1;
     }
 }
 
@@ -688,9 +685,9 @@ int launch_relu_mask(float* d, const float* act, int B, int cols, int d_ld, int 
     return 0;
 }
 
-int launch_sum_parts(const float* p0, const float* p1, const float* p2, const float* p3,
-                     const float* p4, float* out, int B, int cols, int cols4, hipStream_t s) {
-    sum_parts_kernel<<<cdiv(B * cols, 256), 256, 0, s>>>(p0, p1, p2, p3, p4, out, B, cols, cols4);
+int launch_sum_parts(const SumParts& parts, float* out, int B, int cols, int cols_tail, hipStream_t s) {
+    CILRS_CHECK(parts.n >= 1 && parts.n <= kMaxCmd && parts.tail, "sum_parts: bad part list");
+    sum_parts_kernel<<<cdiv(B * cols, 256), 256, 0, s>>>(parts, out, B, cols, cols_tail);
     CILRS_LAUNCH_CHECK();
     return 0;
 }
@@ -713,6 +710,7 @@ int launch_heads_small_pre(const float* feat, int HW, const float* speed, const 
 
 int launch_heads_small_layer(const HeadsSmallArgs& a, hipStream_t s) {
     CILRS_CHECK(a.B >= 1 && a.B <= kHeadsSmallMaxB, "heads_small: batch out of range");
+    CILRS_CHECK(a.ncmd >= 1 && a.ncmd <= kMaxCmd, "heads_small: number of commands out of range");
     CILRS_CHECK(a.in[0] % 4 == 0 && a.in[0] <= 768 && a.in[1] % 4 == 0 && a.in[1] <= 768 &&
                     a.x_ld % 4 == 0, "heads_small: bad width");
     heads_small_layer_kernel<<<cdiv(a.out[0] + a.out[1], 4), 256, 0, s>>>(a);

@@ -57,13 +57,14 @@ struct LinT { int in, out; size_t w, b; };
 //            restatement (oracle/resnet50_oracle.py).  Trains in fp32 through the same kernels;
 //            the 16-bit trunks are inference-only.
 struct Arch {
-    int variant = 0;
+    int variant = 0;                    // trunk: 0 ResNet-34 (the reference), 1 ResNet-50 variant
+    int ncmd = 4;                       // control branches = commands (autonomous_drive.py:362)
     int feat = 512;                     // trunk feature width (avg-pool output)
     std::vector<ParamT> params;
     std::vector<BnT> bns;
     std::vector<ConvT> convs;           // convs[0] = stem
     std::vector<BlockT> blocks;
-    LinT se0, se3, br[4][3], sp0, sp3, sp5;
+    LinT se0, se3, br[kMaxCmd][3], sp0, sp3, sp5;
     size_t arena_floats = 0, count = 0, bn_floats = 0;
     size_t seg_begin[6], seg_end[6];    // 0 heads, 1 layer4, 2 layer3, 3 layer2, 4 layer1, 5 stem
 
@@ -109,7 +110,7 @@ struct Arch {
         return l;
     }
 
-    explicit Arch(int variant_) : variant(variant_) {
+    Arch(int variant_, int ncmd_) : variant(variant_), ncmd(ncmd_) {
         const size_t stem_begin = arena_floats;
         add_conv("visual_encoder.0.weight", "visual_encoder.1", 3, 64, 7, 2, 3, 0);
         size_t layer_begin[5];
@@ -151,7 +152,7 @@ struct Arch {
         layer_begin[4] = arena_floats;
         se0 = add_lin("speed_encoder.0", 1, 128);
         se3 = add_lin("speed_encoder.3", 128, 128);
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < ncmd; ++k) {
             const std::string p = "control_branches." + std::to_string(k);
             br[k][0] = add_lin(p + ".0", feat + 128, 256);
             br[k][1] = add_lin(p + ".3", 256, 256);
@@ -170,9 +171,15 @@ struct Arch {
 };
 
 constexpr int kNumVariants = 2;
-const Arch& arch(int variant = 0) {
-    static const Arch a0(0), a1(1);
-    return variant == 1 ? a1 : a0;
+// variant code = trunk | num_commands << 8 (0 in the upper bits = the reference's 4)
+inline int code_trunk(int code) { return code & 0xff; }
+inline int code_ncmd(int code) { return (code >> 8) == 0 ? 4 : (code >> 8); }
+const Arch& arch(int code = 0) {
+    static std::map<int, Arch*> cache;
+    const int key = code_trunk(code) | (code_ncmd(code) << 8);
+    auto it = cache.find(key);
+    if (it == cache.end()) it = cache.emplace(key, new Arch(code_trunk(code), code_ncmd(code))).first;
+    return *it->second;
 }
 
 const char* kGroupName[5] = {"stem", "layer1", "layer2", "layer3", "layer4"};
@@ -260,8 +267,8 @@ struct cilrs_net {
     int H0, W0, H1, W1;                    // stem conv out, maxpool out
     int featHW;
     // workspace offsets (in floats unless noted)
-    size_t x4, w4, pool, argmax_b /*bytes offset*/, combined, s1, p1, p2, h1[4], h2[4], all_out;
-    size_t dcombined, ds1, dp1, dp2, dh1[4], dh2[4], dcomb_part[5], d_all, speed_in,
+    size_t x4, w4, pool, argmax_b /*bytes offset*/, combined, s1, p1, p2, h1[kMaxCmd], h2[kMaxCmd], all_out;
+    size_t dcombined, ds1, dp1, dp2, dh1[kMaxCmd], dh2[kMaxCmd], dcomb_part[kMaxCmd + 1], d_all, speed_in,
         cmd_b /*bytes offset*/;
     size_t tile_cnt;                       // split-K ticket counters (ints), then 2 x kBnSyncInts ints:
                                            // forward / backward finalize-in-apply counters
@@ -663,7 +670,10 @@ size_t cilrs_param_count(void) { return arch().count; }
 size_t cilrs_bn_arena_floats(void) { return arch().bn_floats; }
 
 int cilrs_num_variants(void) { return kNumVariants; }
-static bool variant_ok(int v) { return v >= 0 && v < kNumVariants; }
+static bool variant_ok(int v) {
+    return v >= 0 && code_trunk(v) < kNumVariants && (v >> 16) == 0 && code_ncmd(v) >= 1 &&
+           code_ncmd(v) <= kMaxCmd;
+}
 int cilrs_variant_num_params(int variant) {
     return variant_ok(variant) ? (int)arch(variant).params.size() : -1;
 }
@@ -845,21 +855,22 @@ int cilrs_net_create_ex(int variant, int batch, int height, int width, unsigned 
     n->s1 = bump.take((size_t)B * 128);
     n->p1 = bump.take((size_t)B * 256);
     n->p2 = bump.take((size_t)B * 256);
-    for (int k = 0; k < 4; ++k) {
+    const int NC = A.ncmd;
+    for (int k = 0; k < NC; ++k) {
         n->h1[k] = bump.take((size_t)B * 256);
         n->h2[k] = bump.take((size_t)B * 256);
     }
-    n->all_out = bump.take((size_t)4 * B * 4);
+    n->all_out = bump.take((size_t)NC * B * 4);
     n->dcombined = bump.take(trainable ? (size_t)B * comb : 4);
     n->ds1 = bump.take(trainable ? (size_t)B * 128 : 4);
     n->dp1 = bump.take(trainable ? (size_t)B * 256 : 4);
     n->dp2 = bump.take(trainable ? (size_t)B * 256 : 4);
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < NC; ++k) {
         n->dh1[k] = bump.take(trainable ? (size_t)B * 256 : 4);
         n->dh2[k] = bump.take(trainable ? (size_t)B * 256 : 4);
     }
-    for (int k = 0; k < 5; ++k) n->dcomb_part[k] = bump.take(trainable ? (size_t)B * comb : 4);
-    n->d_all = bump.take((size_t)4 * B * 4);
+    for (int k = 0; k <= NC; ++k) n->dcomb_part[k] = bump.take(trainable ? (size_t)B * comb : 4);
+    n->d_all = bump.take((size_t)NC * B * 4);
     n->speed_in = bump.take((size_t)B);
     n->cmd_b = bump.take((size_t)B * 2) * sizeof(float);
     // the heads' wide linears also use the wgrad slabs
@@ -988,7 +999,7 @@ int cilrs_net_create_ex(int variant, int batch, int height, int width, unsigned 
             }
         }
     }
-    if (batch == 1 && variant == 0) {
+    if (batch == 1 && code_trunk(variant) == 0 && A.ncmd == 4) {     // (the persistent kernel is built for the reference's 4 commands)
         n->b1_table = bump.take(kB1MaxStages * sizeof(B1Stage) / sizeof(float));
         n->b1_sync = bump.take(kB1SyncInts);
         n->b1_cmd = bump.take(16);
@@ -1332,15 +1343,16 @@ static int forward_from_x4(cilrs_net* net, const cilrs_buffers* bufs, const floa
         HeadsSmallArgs h;
         memset(&h, 0, sizeof(h));
         h.B = B;
+        h.ncmd = A.ncmd;
         h.cmd = reinterpret_cast<const long long*>(command);
         for (int layer = 0; layer < 3; ++layer) {
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < A.ncmd; ++k) {
                 h.w[k] = P + A.br[k][layer].w;
                 h.b[k] = P + A.br[k][layer].b;
             }
             const LinT& sp = layer == 0 ? A.sp0 : layer == 1 ? A.sp3 : A.sp5;
-            h.w[4] = P + sp.w;
-            h.b[4] = P + sp.b;
+            h.w[A.ncmd] = P + sp.w;
+            h.b[A.ncmd] = P + sp.b;
             h.in[0] = A.br[0][layer].in;
             h.in[1] = sp.in;
             h.x_ld = h.in[0];
@@ -1397,24 +1409,27 @@ static int forward_from_x4(cilrs_net* net, const cilrs_buffers* bufs, const floa
     if (run_fwd(h, 1, 1)) return 1;
     fwd_group(h.g[0], ws + net->s1, 128, A.se3, ws + net->combined + feat, comb, kNoDrop);
     if (run_fwd(h, 1, 1)) return 1;
-    // ---- 4 branches (all evaluated, :394-396) + speed predictor (:383-387, 393), layer by layer
-    for (int k = 0; k < 4; ++k)
+    // ---- the branches (all evaluated, :394-396) + speed predictor (:383-387, 393), layer by layer;
+    //      dropout streams: 1 + 2k / 2 + 2k for branch k, 2 NC + 1 for the speed predictor (= 9 for
+    //      the reference's four commands)
+    const int NC = A.ncmd;
+    for (int k = 0; k < NC; ++k)
         fwd_group(h.g[k], ws + net->combined, comb, A.br[k][0], ws + net->h1[k], 256, 1 + 2 * k);
-    fwd_group(h.g[4], ws + net->combined, comb, A.sp0, ws + net->p1, 256, 9);
-    if (run_fwd(h, 5, 1)) return 1;
-    for (int k = 0; k < 4; ++k)
+    fwd_group(h.g[NC], ws + net->combined, comb, A.sp0, ws + net->p1, 256, 2 * NC + 1);
+    if (run_fwd(h, NC + 1, 1)) return 1;
+    for (int k = 0; k < NC; ++k)
         fwd_group(h.g[k], ws + net->h1[k], 256, A.br[k][1], ws + net->h2[k], 256, 2 + 2 * k);
-    fwd_group(h.g[4], ws + net->p1, 256, A.sp3, ws + net->p2, 256, kNoDrop);
-    if (run_fwd(h, 5, 1)) return 1;
-    for (int k = 0; k < 4; ++k)
+    fwd_group(h.g[NC], ws + net->p1, 256, A.sp3, ws + net->p2, 256, kNoDrop);
+    if (run_fwd(h, NC + 1, 1)) return 1;
+    for (int k = 0; k < NC; ++k)
         fwd_group(h.g[k], ws + net->h2[k], 256, A.br[k][2], ws + net->all_out + (size_t)k * B * 4,
                   4, kNoDrop);
-    fwd_group(h.g[4], ws + net->p2, 256, A.sp5, pred_speed, 1, kNoDrop);
-    if (run_fwd(h, 5, 0)) return 1;
+    fwd_group(h.g[NC], ws + net->p2, 256, A.sp5, pred_speed, 1, kNoDrop);
+    if (run_fwd(h, NC + 1, 0)) return 1;
     // gathered by command (:397-398)
     RUN(net, "heads_fwd", 0.0, 0.0, s,
         launch_branch_gather(ws + net->all_out, reinterpret_cast<const long long*>(command),
-                             controls, B, 4, status, s));
+                             controls, B, NC, status, s));
     net->trained_fwd = train != 0;
     net->last_dropout = pdrop;
     return 0;
@@ -2145,43 +2160,46 @@ static int backward_heads(cilrs_net* net, const cilrs_buffers* bufs, const float
     memset(&h, 0, sizeof(h));
 
     // ---- only the commanded branch of each frame receives gradient (gather) ----
+    const int NC = A.ncmd;
     RUN(net, "heads_bwd", 0.0, 0.0, s,
-        launch_branch_scatter(dcontrols, cmd, ws + net->d_all, B, 4, s));
-    const float* d_out[4];
-    for (int k = 0; k < 4; ++k) d_out[k] = ws + net->d_all + (size_t)k * B * 4;
+        launch_branch_scatter(dcontrols, cmd, ws + net->d_all, B, NC, s));
+    const float* d_out[kMaxCmd];
+    for (int k = 0; k < NC; ++k) d_out[k] = ws + net->d_all + (size_t)k * B * 4;
 
     // ---- output layers (256 -> 3 per branch, 256 -> 1 speed predictor) ----
-    for (int k = 0; k < 4; ++k) wg(h.g[k], d_out[k], 4, ws + net->h2[k], 256, A.br[k][2]);
-    wg(h.g[4], dps, 1, ws + net->p2, 256, A.sp5);
-    if (run(2, h, 5)) return 1;
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < NC; ++k) wg(h.g[k], d_out[k], 4, ws + net->h2[k], 256, A.br[k][2]);
+    wg(h.g[NC], dps, 1, ws + net->p2, 256, A.sp5);
+    if (run(2, h, NC + 1)) return 1;
+    for (int k = 0; k < NC; ++k)
         dg(h.g[k], d_out[k], 4, A.br[k][2], ws + net->dh2[k], 256, ws + net->h2[k], 256, dscale);
-    dg(h.g[4], dps, 1, A.sp5, ws + net->dp2, 256, ws + net->p2, 256, 1.0f);
-    if (run(1, h, 5)) return 1;
+    dg(h.g[NC], dps, 1, A.sp5, ws + net->dp2, 256, ws + net->p2, 256, 1.0f);
+    if (run(1, h, NC + 1)) return 1;
     // ---- middle layers (256 -> 256) ----
-    for (int k = 0; k < 4; ++k) wg(h.g[k], ws + net->dh2[k], 256, ws + net->h1[k], 256, A.br[k][1]);
-    wg(h.g[4], ws + net->dp2, 256, ws + net->p1, 256, A.sp3);
-    if (run(2, h, 5)) return 1;
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < NC; ++k) wg(h.g[k], ws + net->dh2[k], 256, ws + net->h1[k], 256, A.br[k][1]);
+    wg(h.g[NC], ws + net->dp2, 256, ws + net->p1, 256, A.sp3);
+    if (run(2, h, NC + 1)) return 1;
+    for (int k = 0; k < NC; ++k)
         dg(h.g[k], ws + net->dh2[k], 256, A.br[k][1], ws + net->dh1[k], 256, ws + net->h1[k], 256,
            dscale);
-    dg(h.g[4], ws + net->dp2, 256, A.sp3, ws + net->dp1, 256, ws + net->p1, 256, dscale);
-    if (run(1, h, 5)) return 1;
+    dg(h.g[NC], ws + net->dp2, 256, A.sp3, ws + net->dp1, 256, ws + net->p1, 256, dscale);
+    if (run(1, h, NC + 1)) return 1;
     // ---- first layers (feat+128 -> 256 per branch; feat -> 256 speed predictor, visual half
     //      only; 640 / 512 for the reference's ResNet-34 trunk) ----
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < NC; ++k)
         wg(h.g[k], ws + net->dh1[k], 256, ws + net->combined, comb, A.br[k][0]);
-    wg(h.g[4], ws + net->dp1, 256, ws + net->combined, comb, A.sp0);
-    if (run(2, h, 5)) return 1;
-    for (int k = 0; k < 4; ++k)
+    wg(h.g[NC], ws + net->dp1, 256, ws + net->combined, comb, A.sp0);
+    if (run(2, h, NC + 1)) return 1;
+    for (int k = 0; k < NC; ++k)
         dg(h.g[k], ws + net->dh1[k], 256, A.br[k][0], ws + net->dcomb_part[k], comb, nullptr, 0, 1.f);
-    dg(h.g[4], ws + net->dp1, 256, A.sp0, ws + net->dcomb_part[4], comb, nullptr, 0, 1.f);
-    if (run(1, h, 5)) return 1;
-    // d combined = sum of the four branch contributions (comb wide) + speed predictor (feat wide)
-    RUN(net, "heads_bwd", 0.0, 0.0, s,
-        launch_sum_parts(ws + net->dcomb_part[0], ws + net->dcomb_part[1],
-                         ws + net->dcomb_part[2], ws + net->dcomb_part[3],
-                         ws + net->dcomb_part[4], dcomb, B, comb, feat, s));
+    dg(h.g[NC], ws + net->dp1, 256, A.sp0, ws + net->dcomb_part[NC], comb, nullptr, 0, 1.f);
+    if (run(1, h, NC + 1)) return 1;
+    // d combined = sum of the branch contributions (comb wide) + speed predictor (feat wide)
+    SumParts parts;
+    memset(&parts, 0, sizeof(parts));
+    parts.n = NC;
+    for (int k = 0; k < NC; ++k) parts.p[k] = ws + net->dcomb_part[k];
+    parts.tail = ws + net->dcomb_part[NC];
+    RUN(net, "heads_bwd", 0.0, 0.0, s, launch_sum_parts(parts, dcomb, B, comb, feat, s));
     // ---- speed encoder (the speed half of `combined`) ----
     RUN(net, "heads_bwd", 0.0, 0.0, s,
         launch_relu_mask(dcomb + feat, ws + net->combined + feat, B, 128, comb, comb, 1.0f, s));

