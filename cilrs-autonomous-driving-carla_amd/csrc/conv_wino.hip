@@ -160,8 +160,7 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restri
     }
 }
 
-__global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+__device__ __forceinline__ void wino_full_body(const WinoArgs& a, float* smem, const int bid) {
     constexpr int STAGE = 16 * WT * WP + 16 * WK * WP;      // floats per stage (64 KB)
     float* Vs = smem;                          // [2 stages]: [16][WT][WP] | [16][WK][WP]
     float* Us = smem + 16 * WT * WP;
@@ -171,7 +170,7 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
     const int TH = (a.H + 1) >> 1, TW = (a.W + 1) >> 1;
     const int tiles_img = TH * TW, total_tiles = a.N * tiles_img;
     const int nkt = a.K / WK;
-    const int blk_n = blockIdx.x % nkt, blk_m = blockIdx.x / nkt;
+    const int blk_n = bid % nkt, blk_m = bid / nkt;
     const int k0 = blk_n * WK;
     const int nchunks = a.C / WC;
 
@@ -272,7 +271,7 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
 #pragma unroll
         for (int m = 0; m < 2; ++m) acc[x][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const long long tm_start = (a.stamps != nullptr && blockIdx.x == 0) ? __builtin_amdgcn_s_memtime() : 0;
+    const long long tm_start = (a.stamps != nullptr && bid == 0) ? __builtin_amdgcn_s_memtime() : 0;
     load_chunk(0);
     store_chunk(0);
     if (nchunks > 1) load_chunk(1);
@@ -336,7 +335,7 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
     // launch, in shader cycles: [prologue, first phase incl. its barrier, second phase, end
     // barrier, epilogue, K loop]
     long long tm_a = 0, tm_b = 0, tm_bar = 0;
-    const bool stamp = a.stamps != nullptr && blockIdx.x == 0 && (tid == 0 || tid == 256);
+    const bool stamp = a.stamps != nullptr && bid == 0 && (tid == 0 || tid == 256);
     const long long tm0 = tm_start;
     long long tm_loop0 = 0;
     if (stamp) tm_loop0 = __builtin_amdgcn_s_memtime();
@@ -484,8 +483,7 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a) {
 constexpr int QT = 16;
 constexpr int QSTAGE = 16 * QT * WP + 16 * WK * WP;          // floats per stage (40 KB)
 constexpr size_t kWinoQLds = (size_t)2 * QSTAGE * sizeof(float);
-__global__ __launch_bounds__(WTHREADS) void conv_wino_q_kernel(const WinoArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+__device__ __forceinline__ void wino_q_body(const WinoArgs& a, float* smem, const int bid) {
     float* Vs = smem;                          // [2 stages]: [16][QT][WP] | [16][WK][WP]
     float* Us = smem + 16 * QT * WP;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -494,7 +492,7 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_q_kernel(const WinoArgs a)
     const int TH = (a.H + 1) >> 1, TW = (a.W + 1) >> 1;
     const int tiles_img = TH * TW, total_tiles = a.N * tiles_img;
     const int nkt = a.K / WK;
-    const int blk_n = blockIdx.x % nkt, blk_m = blockIdx.x / nkt;
+    const int blk_n = bid % nkt, blk_m = bid / nkt;
     const int k0 = blk_n * WK;
     const int nchunks = a.C / WC;
     const int tile0 = a.tile_begin + blk_m * QT;
@@ -608,34 +606,24 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_q_kernel(const WinoArgs a)
         }
     };
 
-    f32x2 dA[16], dB[16];
-    f32x4 uA[8], uB[8];
+    // (ONE register set for the producers: in the merged launch below the 16-tile path shares its
+    //  register allocation with the 64-tile path, and two sets spilled 36 VGPRs into its loop)
+    f32x2 dA[16];
+    f32x4 uA[8];
     if (!consumer) {
         load_set(dA, uA, 0);
-        if (nchunks > 1) load_set(dB, uB, 1);
         store_set(dA, uA, 0);
-        if (nchunks > 2) load_set(dA, uA, 2);
+        if (nchunks > 1) load_set(dA, uA, 1);
     }
     __syncthreads();
-    // iteration ch: consumers multiply stage ch & 1; producers store chunk ch + 1 (loaded two
-    // iterations ago) into the other stage and put chunk ch + 3 in flight in the set just freed
-    for (int ch = 0; ch < nchunks; ch += 2) {
+    for (int ch = 0; ch < nchunks; ++ch) {
         if (consumer) {
             multiply(ch);
         } else if (ch + 1 < nchunks) {
-            store_set(dB, uB, 1);
-            if (ch + 3 < nchunks) load_set(dB, uB, ch + 3);
+            store_set(dA, uA, (ch + 1) & 1);
+            if (ch + 2 < nchunks) load_set(dA, uA, ch + 2);
         }
         __syncthreads();
-        if (ch + 1 < nchunks) {
-            if (consumer) {
-                multiply(ch + 1);
-            } else if (ch + 2 < nchunks) {
-                store_set(dA, uA, 0);
-                if (ch + 4 < nchunks) load_set(dA, uA, ch + 4);
-            }
-            __syncthreads();
-        }
     }
 
     // ---- epilogue (consumers): this lane's tile and 4 consecutive channels ----
@@ -726,6 +714,16 @@ __global__ __launch_bounds__(WTHREADS) void conv_wino_q_kernel(const WinoArgs a)
             dst[(size_t)(which * a.K + k0 + col) * a.rows + a.row0 + blk_m] = s;
         }
     }
+}
+
+// One launch = the 64-tile blocks followed by the 16-tile tail blocks: the tail is dispatched as the
+// CUs of the last full round drain, with no kernel boundary (and, in the overlapped backward pass, no
+// extra event dependency) in between.
+__global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a, const WinoArgs tail,
+                                                             const int nfull) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if ((int)blockIdx.x < nfull) wino_full_body(a, smem, (int)blockIdx.x);
+    else wino_q_body(tail, smem, (int)blockIdx.x - nfull);
 }
 
 // ---- weight gradient in the Winograd domain ---------------------------------------------------------
@@ -971,8 +969,7 @@ int wino_prepare() {
     if (!attr_set) {
         CILRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoLds));
-        CILRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_q_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoQLds));
+
         attr_set = true;
     }
     return 0;
@@ -1019,17 +1016,12 @@ int launch_conv_wino(const WinoArgs& a_in, hipStream_t s) {
     if (wino_prepare()) return 1;
     const WinoSplit sp = wino_split(a.N, a.H, a.W, a.K, a.no_tail);
     a.rows = sp.full + sp.tail;
-    if (sp.full > 0) {
-        a.tile_begin = 0; a.row0 = 0;
-        conv_wino_kernel<<<sp.full * (a.K / WK), WTHREADS, kWinoLds, s>>>(a);
-        CILRS_LAUNCH_CHECK();
-    }
-    if (sp.tail > 0) {
-        a.tile_begin = sp.full * WT; a.row0 = sp.full;
-        a.stamps = nullptr;
-        conv_wino_q_kernel<<<sp.tail * (a.K / WK), WTHREADS, kWinoQLds, s>>>(a);
-        CILRS_LAUNCH_CHECK();
-    }
+    WinoArgs t = a;
+    a.tile_begin = 0; a.row0 = 0;
+    t.tile_begin = sp.full * WT; t.row0 = sp.full; t.stamps = nullptr;
+    const int nfull = sp.full * (a.K / WK), ntail = sp.tail * (a.K / WK);
+    conv_wino_kernel<<<nfull + ntail, WTHREADS, nfull > 0 ? kWinoLds : kWinoQLds, s>>>(a, t, nfull);
+    CILRS_LAUNCH_CHECK();
     return 0;
 }
 
