@@ -189,8 +189,11 @@ class Trainer:
         """mean of batch means + per-command mean |steer error|, like the reference."""
         self.model.eval()
         sums = torch.zeros(6, dtype=torch.float64)
-        cmd_sum = torch.zeros(4, dtype=torch.float64, device=self.eng.device)
-        cmd_cnt = torch.zeros(4, dtype=torch.float64, device=self.eng.device)
+        # (the reference's validate is written for its four commands, nb:566; a model built with more
+        #  branches gets one row per command, named cmd<i> beyond the reference's four names)
+        nc = max(4, int(getattr(self.model, "num_commands", 4)))
+        cmd_sum = torch.zeros(nc, dtype=torch.float64, device=self.eng.device)
+        cmd_cnt = torch.zeros(nc, dtype=torch.float64, device=self.eng.device)
         n = 0
         for imgs, speeds, cmds, tgts in batches:
             pc, ps = self.model(imgs, speeds, cmds)
@@ -208,10 +211,12 @@ class Trainer:
                                                                   device=self.eng.device),
                             cmd_sum, cmd_cnt])
         packed = self.all_reduce_sum(packed)
-        sums, n, cs, cc = packed[:6].cpu(), float(packed[6]), packed[7:11].cpu(), packed[11:15].cpu()
+        sums, n = packed[:6].cpu(), float(packed[6])
+        cs, cc = packed[7:7 + nc].cpu(), packed[7 + nc:7 + 2 * nc].cpu()
         out = {k: float(sums[i]) / max(n, 1.0) for i, k in enumerate(LOSS_KEYS)}
-        cmd_avg = {CMD_NAMES[i]: (float(cs[i] / cc[i]) if cc[i] > 0 else float("nan"))
-                   for i in range(4)}
+        names = [CMD_NAMES.get(i, f"cmd{i}") for i in range(nc)]
+        cmd_avg = {names[i]: (float(cs[i] / cc[i]) if cc[i] > 0 else float("nan"))
+                   for i in range(nc)}
         return out, cmd_avg
 
     def all_reduce_sum(self, t):

@@ -1779,3 +1779,11 @@ def test_num_commands_other_than_four(nc):
     pv = dict(m.named_parameters())
     for n, p in orc.named_parameters():
         _close_params(pv[n].detach().cpu(), p.detach(), cfg.lr, 1)
+
+    # validate(): one row per command (the reference's four names, cmd<i> beyond them)
+    out, cmd_avg = tr.validate([to_dev(imgs, spds, cmds, tgts)])
+    assert len(cmd_avg) == max(4, nc) and all(k in out for k in ("total", "steer"))
+    for i in range(nc):
+        sel = cmds == i
+        name = ["FOLLOW", "LEFT", "RIGHT", "STRAIGHT"][i] if i < 4 else f"cmd{i}"
+        assert sel.any() and cmd_avg[name] == cmd_avg[name]          # present, not NaN
