@@ -12,7 +12,8 @@
 // load by one wave, the other waves wait behind a workgroup barrier).
 // Variants: 0 = one counter; 1 = 8 counters (block & 7), polled by 8 lanes of one wave;
 //           2 = variant 1 + `__threadfence()` on both sides (the fenced form, for comparison);
-//           3 = variant 1 without any payload (the bare barrier).
+//           3 = variant 1 without any payload (the bare barrier);
+//           16 / 32 / 64 = variant 1 with that many counters (polled by as many lanes).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -41,8 +42,8 @@ template <int VARIANT>
 __global__ __launch_bounds__(1024) void probe(int* counters, float* records, int stages, int base,
                                               int* errors, long long* cycles) {
     const int nblk = gridDim.x, b = blockIdx.x, tid = threadIdx.x;
-    const int nshard = VARIANT == 0 ? 1 : 8;
-    const int per_shard = VARIANT == 0 ? nblk : nblk / 8;
+    const int nshard = VARIANT == 0 ? 1 : VARIANT >= 16 ? VARIANT : 8;
+    const int per_shard = nblk / nshard;
     int bad = 0;
     const long long t0 = __builtin_amdgcn_s_memrealtime();
     for (int s = 1; s <= stages; ++s) {
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(1024) void probe(int* counters, float* records, int
         if (tid < 64) {
             if (VARIANT == 2 && tid == 0) __threadfence();
             if (tid == 0)
-                __hip_atomic_fetch_add(&counters[(VARIANT == 0 ? 0 : (b & 7)) * kShardStride], 1,
+                __hip_atomic_fetch_add(&counters[(VARIANT == 0 ? 0 : (b % nshard)) * kShardStride], 1,
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int target = base + s * per_shard;
             int spins = 0;
@@ -85,12 +86,12 @@ __global__ __launch_bounds__(1024) void probe(int* counters, float* records, int
 template <int V>
 void run(const char* name, int blocks, int threads, int stages, int* counters, float* records,
          int* errors, long long* cycles) {
-    CK(hipMemset(counters, 0, 8 * kShardStride * sizeof(int)));
+    CK(hipMemset(counters, 0, 64 * kShardStride * sizeof(int)));
     CK(hipMemset(errors, 0, sizeof(int)));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     int base = 0;
-    const int per_shard = V == 0 ? blocks : blocks / 8;
+    const int per_shard = V == 0 ? blocks : V >= 16 ? blocks / V : blocks / 8;
     float best = 1e30f;
     for (int rep = 0; rep < 6; ++rep) {
         CK(hipEventRecord(e0));
@@ -114,7 +115,7 @@ int main(int argc, char** argv) {
     const int threads = argc > 2 ? atoi(argv[2]) : 1024;
     const int stages = argc > 3 ? atoi(argv[3]) : 200;
     int* counters; float* records; int* errors; long long* cycles;
-    CK(hipMalloc(&counters, 8 * kShardStride * sizeof(int)));
+    CK(hipMalloc(&counters, 64 * kShardStride * sizeof(int)));
     CK(hipMalloc(&records, (size_t)blocks * 2048));   // two generations: a record is rewritten two barriers later
     CK(hipMalloc(&errors, sizeof(int)));
     CK(hipMalloc(&cycles, sizeof(long long)));
@@ -125,6 +126,9 @@ int main(int argc, char** argv) {
     run<0>("1 KB sc1 record + barrier, one counter", blocks, threads, stages, counters, records, errors, cycles);
     run<1>("1 KB sc1 record + barrier, 8 sharded counters", blocks, threads, stages, counters, records, errors, cycles);
     run<2>("same + __threadfence() on both sides", blocks, threads, stages, counters, records, errors, cycles);
+    run<16>("1 KB sc1 record + barrier, 16 sharded counters", blocks, threads, stages, counters, records, errors, cycles);
+    run<32>("1 KB sc1 record + barrier, 32 sharded counters", blocks, threads, stages, counters, records, errors, cycles);
+    run<64>("1 KB sc1 record + barrier, 64 sharded counters", blocks, threads, stages, counters, records, errors, cycles);
     // launch-boundary reference: the same number of trivial dependent kernels
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
