@@ -75,6 +75,7 @@ SIGNATURES = {
     "cilrs_net_forward_u8_b1_post": (i32, [vp, C.POINTER(Buffers), vp, vp, vp, vp, vp, vp, i32, vp]),
     "cilrs_net_forward_u8_b1_sync": (i32, [vp, C.POINTER(Buffers), vp, vp, vp, vp, vp, vp]),
     "cilrs_net_b1_stages": (i32, [vp]),
+    "cilrs_net_b1_set_epoch": (i32, [vp, C.POINTER(Buffers), i32, vp]),
     "cilrs_net_wino_convs": (i32, [vp]),
     "cilrs_net_b1_stage_us": (i32, [vp, C.POINTER(Buffers), c_float_p, c_float_p, i32]),
     "cilrs_net_forward_u8_bf16": (i32, [vp, C.POINTER(Buffers), vp, vp, vp, vp, vp, vp]),

@@ -99,12 +99,28 @@ class Plan:
         except Exception:
             pass
 
+    def take_status(self):
+        """Synchronising read-and-clear of the status words: (bad_command, barrier_gave_up)."""
+        dev = self.workspace.device
+        torch.cuda.synchronize(dev)
+        st = self.status.tolist()
+        if st[0] != 0 or st[1] != 0:
+            self.status.zero_()
+            torch.cuda.synchronize(dev)
+        return st[0] != 0, st[1] != 0
+
     def check_status(self):
         """Synchronising read of the status words of the last forward on this plan; raises what
         the reference's ``all_out.gather(0, idx)`` raises for an out-of-range command."""
+        # forwards may have run on other streams than torch's current one (Predictor, inference
+        # lanes): wait for the whole device before reading, and again after clearing, so that a
+        # set racing the clear cannot be lost
+        dev = self.workspace.device
+        torch.cuda.synchronize(dev)
         st = self.status.tolist()
         if st[0] != 0 or st[1] != 0:
             self.status.zero_()           # the words are sticky: "since the last check"
+            torch.cuda.synchronize(dev)
         if st[1] != 0:
             raise RuntimeError("CILRS persistent forward: a grid barrier gave up (another "
                                "persistent launch was holding the device); outputs are NaN")

@@ -24,6 +24,17 @@ IMG_WIDTH, IMG_HEIGHT = 200, 88        # :483-484
 SPEED_NORM_FACTOR = 90.0               # :485
 
 
+class _FastTick:
+    """Everything one persistent tick hands to the library, bound once per weight epoch."""
+    __slots__ = ("sync_fn", "post_fn", "handle", "bufs", "frame", "speed", "cmd", "ctrl", "spd",
+                 "stream", "plan", "done")
+
+
+# ticks served through the per-layer launches after a barrier timeout before the persistent launch
+# is tried again (10 s of a 20 Hz control loop)
+DEGRADED_TICKS = 200
+
+
 class Predictor:
     """Holds pinned staging buffers so a 20 Hz control loop does one H2D and one D2H copy per
     tick (the reference does four ``.item()`` syncs, :918-920).  ``use_graph=True`` replays the
@@ -81,6 +92,11 @@ class Predictor:
         self._cmd_np = self.cmd_host.numpy()
         self._seen_epoch = -1
         self._fast = None
+        # degraded mode of the persistent launch (see _barrier_gave_up)
+        self.degraded_ticks_left = 0
+        self.barrier_timeouts = 0
+        self._warned_degraded = False
+        self._inject_timeout = 0      # tests: simulate this many barrier timeouts
 
     def _order_after_weight_updates(self):
         # The forward runs on this predictor's own stream.  Whatever last wrote the weights (a
@@ -152,6 +168,9 @@ class Predictor:
             np.asarray(speeds_kmh, dtype=np.float64) / SPEED_NORM_FACTOR, 1.0)
         np.copyto(self._cmd_np, self._check_commands(commands))
         eng = self.eng
+        if self.degraded_ticks_left > 0:
+            self.degraded_ticks_left -= 1
+            return self._tick_per_layer()
         fast = self._fast
         if fast is None or self._seen_epoch != eng.weights_epoch:
             self._order_after_weight_updates()
@@ -159,17 +178,21 @@ class Predictor:
             eng._announce_weights(pl)
             eng.last_plan = pl
             L = _L
-            fast = self._fast = (L.lib().cilrs_net_forward_u8_b1_sync, pl.handle, _C.byref(pl.bufs),
-                                 L.ptr(self.frames_host), L.ptr(self.speed_host),
-                                 L.ptr(self.cmd_host), L.ptr(self._ctrl_host), L.ptr(self._spd_host),
-                                 _C.c_void_p(self.stream.cuda_stream), pl,
-                                 L.lib().cilrs_net_forward_u8_b1_post, L.ptr(self._done_host))
+            fast = self._fast = _FastTick()
+            fast.sync_fn = L.lib().cilrs_net_forward_u8_b1_sync
+            fast.post_fn = L.lib().cilrs_net_forward_u8_b1_post
+            fast.handle, fast.bufs, fast.plan = pl.handle, _C.byref(pl.bufs), pl
+            fast.frame, fast.speed, fast.cmd = (L.ptr(self.frames_host), L.ptr(self.speed_host),
+                                                L.ptr(self.cmd_host))
+            fast.ctrl, fast.spd = L.ptr(self._ctrl_host), L.ptr(self._spd_host)
+            fast.stream = _C.c_void_p(self.stream.cuda_stream)
+            fast.done = L.ptr(self._done_host)
         if self.spin:
             # the launch posts its own completion word behind the outputs: spin on it instead of
             # waiting for the stream's completion signal
             self._seq = seq = (self._seq % 0x3FFFFFFF) + 1
-            if fast[10](fast[1], fast[2], fast[3], fast[4], fast[5], fast[6], fast[7], fast[11], seq,
-                        fast[8]) != 0:
+            if fast.post_fn(fast.handle, fast.bufs, fast.frame, fast.speed, fast.cmd, fast.ctrl,
+                            fast.spd, fast.done, seq, fast.stream) != 0:
                 _L.check(1)
             done, n = self._done_np, 0
             while done[0] != seq:
@@ -177,10 +200,57 @@ class Predictor:
                 if n > 2000000:             # ~seconds: something is wrong; let the stream tell us
                     self.stream.synchronize()
                     break
-        elif fast[0](*fast[1:9]) != 0:
+        elif fast.sync_fn(fast.handle, fast.bufs, fast.frame, fast.speed, fast.cmd, fast.ctrl,
+                          fast.spd, fast.stream) != 0:
             _L.check(1)
-        if not np.isfinite(self._ctrl_np).all():
-            eng.check_status()            # a grid barrier that gave up leaves NaN outputs
+        if self._inject_timeout > 0:      # test hook: what the kernel leaves behind on a timeout
+            self._inject_timeout -= 1
+            self.stream.synchronize()
+            fast.plan.status[1] = 1
+            self._ctrl_np[...] = np.nan
+            self._spd_np[...] = np.nan
+        if not np.isfinite(self._ctrl_np).all() and self._barrier_gave_up(fast.plan):
+            return self._tick_per_layer()
+        out = np.empty((self.batch, 4), dtype=np.float32)
+        out[:, :3] = self._ctrl_np
+        out[:, 3] = self._spd_np * np.float32(SPEED_NORM_FACTOR)                # :920
+        return out
+
+    def _barrier_gave_up(self, plan):
+        """Non-finite outputs of the persistent launch.  If its status word says a grid barrier
+        gave up (another resident kernel held CUs: the launch cannot make progress while it is
+        not fully resident), this is not an error of the frame: the reference's control loop never
+        raises mid-drive (model/autonomous_drive.py:908-920), so the tick is served through the
+        per-layer launches in the same process, the next DEGRADED_TICKS ticks too, and a warning is
+        printed once.  Anything else (a bad command, NaN weights) goes through check_status."""
+        bad_cmd, barrier = plan.take_status()
+        if not barrier:
+            if bad_cmd:
+                plan.status[0] = 1
+                self.eng.check_status()
+            return False
+        if bad_cmd:
+            plan.status[0] = 1            # keep the other finding for the next check
+        self.barrier_timeouts += 1
+        self.degraded_ticks_left = DEGRADED_TICKS
+        if not self._warned_degraded:
+            self._warned_degraded = True
+            import warnings
+            warnings.warn("CILRS Predictor: a grid barrier of the persistent single-frame launch gave "
+                          "up (another kernel was resident on the device); serving this and the next "
+                          f"{DEGRADED_TICKS} ticks through per-layer launches", RuntimeWarning)
+        return True
+
+    def _tick_per_layer(self):
+        """The staged inputs through the per-layer launch path (device staging buffers)."""
+        self._order_after_weight_updates()
+        with torch.cuda.stream(self.stream):
+            self.in_dev.copy_(self.in_host, non_blocking=True)
+            self.eng.run_forward_u8(self.frames_dev, self.speed_dev, self.cmd_dev,
+                                    out=(self.ctrl_dev, self.spd_out_dev), graph=self.use_graph,
+                                    half=self.half, persistent=False)
+            self.out_host[:self.batch * 4].copy_(self.out_dev, non_blocking=True)
+            self.stream.synchronize()
         out = np.empty((self.batch, 4), dtype=np.float32)
         out[:, :3] = self._ctrl_np
         out[:, 3] = self._spd_np * np.float32(SPEED_NORM_FACTOR)                # :920
@@ -217,7 +287,9 @@ class Predictor:
         np.copyto(cam[1][0][0], frame)
         cam[1][1][...] = min(float(speed_kmh) / SPEED_NORM_FACTOR, 1.0)
         cam[1][2][...] = self._check_commands([int(command_idx)])
-        if self.persistent and self.zero_copy:
+        if self.persistent and self.zero_copy and self.degraded_ticks_left > 0:
+            self.degraded_ticks_left -= 1
+        elif self.persistent and self.zero_copy:
             # the transform kernel samples the pinned camera frame in place (it touches a fraction
             # of its 1.9 MB), the persistent launch starts at its second stage; one library call
             eng = self.eng
@@ -233,11 +305,11 @@ class Predictor:
                 pl.handle, _C.byref(pl.bufs), _L.ptr(cam[0]), hs, ws_, px, ws_ * px,
                 _L.ptr(cam[4][0]), _L.ptr(cam[4][1]), _L.ptr(self._ctrl_host),
                 _L.ptr(self._spd_host), 1, _C.c_void_p(self.stream.cuda_stream)))
-            if not np.isfinite(self._ctrl_np).all():
-                eng.check_status()
-            c = self._ctrl_np[0]
-            return (float(c[0]), float(c[1]), float(c[2]),
-                    float(self._spd_np[0]) * SPEED_NORM_FACTOR)
+            if np.isfinite(self._ctrl_np).all() or not self._barrier_gave_up(pl):
+                c = self._ctrl_np[0]
+                return (float(c[0]), float(c[1]), float(c[2]),
+                        float(self._spd_np[0]) * SPEED_NORM_FACTOR)
+            # (barrier timeout: fall through to the per-layer camera path below)
         self._order_after_weight_updates()
         with torch.cuda.stream(self.stream):
             cam[2][0].copy_(cam[0], non_blocking=True)               # frame | speed | command

@@ -185,7 +185,8 @@ __device__ __forceinline__ bool wait_channels(const int* sync, const int target)
         int spins = 0, ok = 1;
         while (true) {
             int here = 1;
-            if (threadIdx.x < 8) here = (ld_int_sc1(&sync[threadIdx.x * kBnShardStride]) - target) >= 0;
+            if (threadIdx.x < 8)      // unsigned difference: wrap-safe (see infer_b1.hip grid_wait)
+                here = (int)((unsigned)ld_int_sc1(&sync[threadIdx.x * kBnShardStride]) - (unsigned)target) >= 0;
             if (__all(here)) break;
             if (++spins > kBnSpinLimit) { ok = 0; break; }
             __builtin_amdgcn_s_sleep(1);
@@ -857,6 +858,237 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restric
     }
 }
 
+// ---- 16-bit tensors end to end (bf16 training mode, round 4) --------------------------------------
+// The same three passes on bf16 NHWC tensors: 8 channels = 16 bytes per lane, fp32 arithmetic, fp32
+// statistics / coefficients, results rounded to bf16 once on the way out.  BatchNorm here is
+// exactly the fp32 BatchNorm of the STORED (rounded) convolution output.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void cvt8(const bf16x8 v, f32x4& lo, f32x4& hi) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        lo[e] = (float)v[e];
+        hi[e] = (float)v[4 + e];
+    }
+}
+__device__ __forceinline__ bf16x8 pack8(const f32x4 lo, const f32x4 hi) {
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        o[e] = (__bf16)lo[e];
+        o[4 + e] = (__bf16)hi[e];
+    }
+    return o;
+}
+
+// partial layout and modes of bn_colreduce_kernel; a thread owns 8 channels of its rows
+template <int MODE>
+__global__ __launch_bounds__(256) void bn16_colreduce_kernel(
+    const __bf16* __restrict__ y, const __bf16* __restrict__ dz, const __bf16* __restrict__ z,
+    const float* __restrict__ stats, float* __restrict__ partial, const int M, const int C,
+    const int relu, const int rows_per_block) {
+    __shared__ float red[2][256 * 8];
+    const int Cg = C > 2048 ? 2048 : C;
+    const int c0 = blockIdx.y * Cg;
+    const int tpr = Cg >> 3;               // threads per row
+    const int rpi = 256 / tpr;             // rows per iteration
+    const int q = threadIdx.x % tpr, rsub = threadIdx.x / tpr;
+    const int row_begin = blockIdx.x * rows_per_block;
+    const int row_end = min(M, row_begin + rows_per_block);
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 mlo = zero, mhi = zero, rlo = zero, rhi = zero;
+    if (MODE == 1) {
+        mlo = *reinterpret_cast<const f32x4*>(stats + c0 + q * 8);
+        mhi = *reinterpret_cast<const f32x4*>(stats + c0 + q * 8 + 4);
+        rlo = *reinterpret_cast<const f32x4*>(stats + C + c0 + q * 8);
+        rhi = *reinterpret_cast<const f32x4*>(stats + C + c0 + q * 8 + 4);
+    }
+    f32x4 a1lo[2], a1hi[2], a2lo[2], a2hi[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) a1lo[u] = a1hi[u] = a2lo[u] = a2hi[u] = zero;
+    auto accum = [&](const int r, const int u) {
+        const size_t o = (size_t)r * C + c0 + q * 8;
+        f32x4 vlo, vhi;
+        cvt8(*reinterpret_cast<const bf16x8*>(y + o), vlo, vhi);
+        if (MODE == 0) {
+            a1lo[u] += vlo; a1hi[u] += vhi;
+            a2lo[u] += vlo * vlo; a2hi[u] += vhi * vhi;
+        } else {
+            f32x4 glo, ghi;
+            cvt8(*reinterpret_cast<const bf16x8*>(dz + o), glo, ghi);
+            if (relu) {
+                f32x4 zlo, zhi;
+                cvt8(*reinterpret_cast<const bf16x8*>(z + o), zlo, zhi);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    glo[e] = zlo[e] > 0.f ? glo[e] : 0.f;
+                    ghi[e] = zhi[e] > 0.f ? ghi[e] : 0.f;
+                }
+            }
+            a1lo[u] += glo; a1hi[u] += ghi;
+            a2lo[u] += glo * ((vlo - mlo) * rlo);
+            a2hi[u] += ghi * ((vhi - mhi) * rhi);
+        }
+    };
+    int r = row_begin + rsub;
+    for (; r + rpi < row_end; r += 2 * rpi) {
+        accum(r, 0);
+        accum(r + rpi, 1);
+    }
+    for (; r < row_end; r += rpi) accum(r, 0);
+    const f32x4 s1lo = a1lo[0] + a1lo[1], s1hi = a1hi[0] + a1hi[1];
+    const f32x4 s2lo = a2lo[0] + a2lo[1], s2hi = a2hi[0] + a2hi[1];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        red[0][threadIdx.x * 8 + e] = s1lo[e];
+        red[0][threadIdx.x * 8 + 4 + e] = s1hi[e];
+        red[1][threadIdx.x * 8 + e] = s2lo[e];
+        red[1][threadIdx.x * 8 + 4 + e] = s2hi[e];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < Cg; c += 256) {
+        float a1 = 0.f, a2 = 0.f;
+        const int qq = c >> 3, e = c & 7;
+        for (int rs = 0; rs < rpi; ++rs) {
+            a1 += red[0][(rs * tpr + qq) * 8 + e];
+            a2 += red[1][(rs * tpr + qq) * 8 + e];
+        }
+        partial[(size_t)(c0 + c) * gridDim.x + blockIdx.x] = a1;
+        partial[(size_t)(C + c0 + c) * gridDim.x + blockIdx.x] = a2;
+    }
+}
+
+// z16 = round( relu?( y16 * w + b (+ residual16) ) ).  kU independent 16-byte streams per thread,
+// every load of a trip in flight before the first use (pure HBM streaming).
+__global__ __launch_bounds__(256) void bn16_apply_kernel(const __bf16* __restrict__ y,
+                                                         const float* __restrict__ stats,
+                                                         const __bf16* __restrict__ residual,
+                                                         __bf16* __restrict__ z, const size_t total8,
+                                                         const int C, const int relu) {
+    constexpr int kU = 4;
+    const int cq = C >> 3;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const int qstep = (int)(stride % (size_t)cq);
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int q = (int)(i % (size_t)cq);
+    const float* sw = stats + 2 * C;
+    const float* sb = stats + 3 * C;
+    for (; i < total8; i += kU * stride) {
+        bf16x8 v[kU], r[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const size_t j = i + u * stride;
+            if (j < total8) {
+                v[u] = *reinterpret_cast<const bf16x8*>(y + j * 8);
+                if (residual) r[u] = *reinterpret_cast<const bf16x8*>(residual + j * 8);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const size_t j = i + u * stride;
+            if (j < total8) {
+                f32x4 lo, hi;
+                cvt8(v[u], lo, hi);
+                lo = lo * *reinterpret_cast<const f32x4*>(sw + q * 8) +
+                     *reinterpret_cast<const f32x4*>(sb + q * 8);
+                hi = hi * *reinterpret_cast<const f32x4*>(sw + q * 8 + 4) +
+                     *reinterpret_cast<const f32x4*>(sb + q * 8 + 4);
+                if (residual) {
+                    f32x4 rl, rh;
+                    cvt8(r[u], rl, rh);
+                    lo += rl;
+                    hi += rh;
+                }
+                if (relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        lo[e] = fmaxf(lo[e], 0.f);
+                        hi[e] = fmaxf(hi[e], 0.f);
+                    }
+                }
+                *reinterpret_cast<bf16x8*>(z + j * 8) = pack8(lo, hi);
+            }
+            q += qstep;
+            if (q >= cq) q -= cq;
+        }
+    }
+}
+
+// g = dz16 * (z16 > 0 if relu);  dy16 = round((g - c2 - xhat*c3) * c1), xhat from y16;
+// optionally g_out16 = g (the residual path's gradient: a selection of bf16 values, exact)
+__global__ __launch_bounds__(256) void bn16_bwd_apply_kernel(
+    const __bf16* __restrict__ dz, const __bf16* __restrict__ z, const __bf16* __restrict__ y,
+    const float* __restrict__ stats, const float* __restrict__ coef, __bf16* __restrict__ dy,
+    __bf16* __restrict__ g_out, const size_t total8, const int C, const int relu) {
+    constexpr int kU = 3;
+    const int cq = C >> 3;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const int qstep = (int)(stride % (size_t)cq);
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int q = (int)(i % (size_t)cq);
+    for (; i < total8; i += kU * stride) {
+        bf16x8 gv[kU], zv[kU], yv[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const size_t j = i + u * stride;
+            if (j < total8) {
+                gv[u] = *reinterpret_cast<const bf16x8*>(dz + j * 8);
+                if (relu) zv[u] = *reinterpret_cast<const bf16x8*>(z + j * 8);
+                yv[u] = *reinterpret_cast<const bf16x8*>(y + j * 8);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const size_t j = i + u * stride;
+            if (j < total8) {
+                f32x4 glo, ghi, ylo, yhi;
+                cvt8(gv[u], glo, ghi);
+                cvt8(yv[u], ylo, yhi);
+                if (relu) {
+                    f32x4 zlo, zhi;
+                    cvt8(zv[u], zlo, zhi);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        glo[e] = zlo[e] > 0.f ? glo[e] : 0.f;
+                        ghi[e] = zhi[e] > 0.f ? ghi[e] : 0.f;
+                    }
+                }
+                if (g_out) *reinterpret_cast<bf16x8*>(g_out + j * 8) = pack8(glo, ghi);
+                const f32x4 xl = (ylo - *reinterpret_cast<const f32x4*>(stats + q * 8)) *
+                                 *reinterpret_cast<const f32x4*>(stats + C + q * 8);
+                const f32x4 xh = (yhi - *reinterpret_cast<const f32x4*>(stats + q * 8 + 4)) *
+                                 *reinterpret_cast<const f32x4*>(stats + C + q * 8 + 4);
+                const f32x4 dl = (glo - *reinterpret_cast<const f32x4*>(coef + C + q * 8) -
+                                  xl * *reinterpret_cast<const f32x4*>(coef + 2 * C + q * 8)) *
+                                 *reinterpret_cast<const f32x4*>(coef + q * 8);
+                const f32x4 dh = (ghi - *reinterpret_cast<const f32x4*>(coef + C + q * 8 + 4) -
+                                  xh * *reinterpret_cast<const f32x4*>(coef + 2 * C + q * 8 + 4)) *
+                                 *reinterpret_cast<const f32x4*>(coef + q * 8 + 4);
+                *reinterpret_cast<bf16x8*>(dy + j * 8) = pack8(dl, dh);
+            }
+            q += qstep;
+            if (q >= cq) q -= cq;
+        }
+    }
+}
+
+// AdaptiveAvgPool2d backward into a bf16 gradient tensor
+__global__ __launch_bounds__(256) void avgpool_bwd16_kernel(const float* __restrict__ dout,
+                                                            __bf16* __restrict__ dx, const int N,
+                                                            const int HW, const int C,
+                                                            const int dout_ld) {
+    const int cq = C >> 3;
+    const size_t total = (size_t)N * HW * cq;
+    const float inv = (float)HW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i % cq);
+        const int n = (int)(i / ((size_t)HW * cq));
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(dout + (size_t)n * dout_ld + q * 8);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(dout + (size_t)n * dout_ld + q * 8 + 4);
+        *reinterpret_cast<bf16x8*>(dx + i * 8) = pack8(lo / inv, hi / inv);
+    }
+}
+
 int grid_for(size_t total, int per_block = 256, int cap = 4096) {
     size_t b = (total + per_block - 1) / per_block;
     if (b > (size_t)cap) b = cap;
@@ -915,7 +1147,7 @@ int launch_bn_train_fwd(const float* y, int M, int C, const float* gamma, const 
     }
     if (z && sync && sync->dev && C <= 1024 && C % 8 == 0) {   // finalize as the first job of the apply launch
         const size_t total4 = (size_t)M * C / 4;
-        sync->total += C / 8;
+        sync->total = (int)((unsigned)sync->total + (unsigned)(C / 8));
         const BnFinArgs f{partial, nblk, M, gamma, beta, running_mean, running_var, nbt, momentum, eps,
                           sync->dev, sync->total};
         bn_finalize_apply_kernel<<<grid_for(total4, kApplyThreads, apply_grid_cap()), kApplyThreads, 0, s>>>(
@@ -972,7 +1204,7 @@ int launch_bn_bwd(const float* dz, const float* z, const float* y, int M, int C,
     }
     const size_t total4 = (size_t)M * C / 4;
     if (sync && sync->dev && C <= 1024 && C % 8 == 0) {
-        sync->total += C / 8;
+        sync->total = (int)((unsigned)sync->total + (unsigned)(C / 8));
         const BnBwdFinArgs f{partial, nblk, M, gamma, dgamma, dbeta, accumulate, sync->dev, sync->total};
         bn_bwd_finalize_apply_kernel<<<grid_for(total4, kApplyThreads, apply_grid_cap()), kApplyThreads, 0, s>>>(
             f, dz, z, y, stats, coef, dy, g_out, total4, C, relu, reinterpret_cast<__bf16*>(dy16));
@@ -1060,6 +1292,87 @@ int launch_avgpool_bwd(const float* dout, float* dx, int N, int HW, int C, int d
                        hipStream_t s) {
     const size_t total = (size_t)N * HW * (C / 4);
     avgpool_bwd_kernel<<<grid_for(total), 256, 0, s>>>(dout, dx, N, HW, C, dout_ld);
+    CILRS_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- 16-bit tensors end to end -------------------------------------------------------------------
+static int check_c16(int C) {
+    CILRS_CHECK(C % 8 == 0 && C >= 8 &&
+                    ((C <= 2048 && 256 % (C / 8) == 0) || (C <= 8192 && C % 2048 == 0)),
+                "batchnorm (16-bit): unsupported channel count %d", C);
+    return 0;
+}
+static ColPlan col_plan16(int M, int C) {
+    const int rpi = 256 / ((C > 2048 ? 2048 : C) >> 3);
+    int rows = cdiv(M, kMaxPartBlocks);
+    const int min_rows = 4 * rpi;
+    if (rows < min_rows) rows = min_rows;
+    rows = cdiv(rows, rpi) * rpi;
+    ColPlan p{cdiv(M, rows), rows};
+    return p;
+}
+
+int launch_bn16_train_fwd(const void* y16, int M, int C, const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, long long* nbt, float momentum,
+                          float eps, const void* residual16, int relu, float* stats, float* partial,
+                          void* z16, int pre_nblk, hipStream_t s) {
+    if (check_c16(C)) return 1;
+    const __bf16* y = reinterpret_cast<const __bf16*>(y16);
+    int nblk = pre_nblk;
+    if (nblk <= 0) {
+        const ColPlan p = col_plan16(M, C);
+        bn16_colreduce_kernel<0><<<dim3(p.nblk, C > 2048 ? C / 2048 : 1), 256, 0, s>>>(
+            y, nullptr, nullptr, nullptr, partial, M, C, 0, p.rows_per_block);
+        CILRS_LAUNCH_CHECK();
+        nblk = p.nblk;
+    }
+    bn_fwd_finalize_kernel<<<C, kFinThreads, 0, s>>>(partial, nblk, M, C, gamma, beta, running_mean,
+                                                     running_var, nbt, momentum, eps, stats);
+    CILRS_LAUNCH_CHECK();
+    if (z16) {
+        const size_t total8 = (size_t)M * C / 8;
+        bn16_apply_kernel<<<grid_for(total8, 256 * 4), 256, 0, s>>>(
+            y, stats, reinterpret_cast<const __bf16*>(residual16), reinterpret_cast<__bf16*>(z16),
+            total8, C, relu);
+        CILRS_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+int launch_bn16_bwd(const void* dz16, const void* z16, const void* y16, int M, int C,
+                    const float* gamma, const float* stats, int relu, float* dgamma, float* dbeta,
+                    float* coef, float* partial, void* dy16, void* g_out16, int pre_nblk,
+                    hipStream_t s) {
+    if (check_c16(C)) return 1;
+    CILRS_CHECK(dz16 && y16 && dy16 && (z16 || !relu), "bn16_bwd: NULL tensor");
+    int nblk = pre_nblk;
+    if (nblk <= 0) {
+        const ColPlan p = col_plan16(M, C);
+        bn16_colreduce_kernel<1><<<dim3(p.nblk, C > 2048 ? C / 2048 : 1), 256, 0, s>>>(
+            reinterpret_cast<const __bf16*>(y16), reinterpret_cast<const __bf16*>(dz16),
+            reinterpret_cast<const __bf16*>(z16), stats, partial, M, C, relu, p.rows_per_block);
+        CILRS_LAUNCH_CHECK();
+        nblk = p.nblk;
+    }
+    bn_bwd_finalize_kernel<<<C, kFinThreads, 0, s>>>(partial, nblk, M, C, gamma, stats, dgamma,
+                                                     dbeta, coef, 0);
+    CILRS_LAUNCH_CHECK();
+    const size_t total8 = (size_t)M * C / 8;
+    bn16_bwd_apply_kernel<<<grid_for(total8, 256 * 3), 256, 0, s>>>(
+        reinterpret_cast<const __bf16*>(dz16), reinterpret_cast<const __bf16*>(z16),
+        reinterpret_cast<const __bf16*>(y16), stats, coef, reinterpret_cast<__bf16*>(dy16),
+        reinterpret_cast<__bf16*>(g_out16), total8, C, relu);
+    CILRS_LAUNCH_CHECK();
+    return 0;
+}
+
+int launch_avgpool_bwd16(const float* dout, void* dx16, int N, int HW, int C, int dout_ld,
+                         hipStream_t s) {
+    CILRS_CHECK(C % 8 == 0, "avgpool_bwd16: C %% 8");
+    const size_t total = (size_t)N * HW * (C / 8);
+    avgpool_bwd16_kernel<<<grid_for(total), 256, 0, s>>>(dout, reinterpret_cast<__bf16*>(dx16), N,
+                                                        HW, C, dout_ld);
     CILRS_LAUNCH_CHECK();
     return 0;
 }

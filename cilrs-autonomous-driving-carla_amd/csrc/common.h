@@ -213,6 +213,19 @@ int launch_bn_bwd(const float* dz, const float* z, const float* y, int M, int C,
                   const float* gamma, const float* stats, int relu, float* dgamma, float* dbeta,
                   int accumulate, float* coef, float* partial, float* dy, float* g_out,
                   int pre_nblk, hipStream_t s, void* dy16 = nullptr, BnSync* sync = nullptr);
+// The same passes on bf16 NHWC tensors (bf16 training mode: 16-bit activations and gradients end to
+// end, fp32 statistics and coefficients; C % 8 == 0).  y16 / z16 / residual16 / dz16 / dy16 /
+// g_out16 are bf16; BatchNorm is the fp32 BatchNorm of the stored y16.
+int launch_bn16_train_fwd(const void* y16, int M, int C, const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, long long* nbt, float momentum,
+                          float eps, const void* residual16, int relu, float* stats, float* partial,
+                          void* z16, int pre_nblk, hipStream_t s);
+int launch_bn16_bwd(const void* dz16, const void* z16, const void* y16, int M, int C,
+                    const float* gamma, const float* stats, int relu, float* dgamma, float* dbeta,
+                    float* coef, float* partial, void* dy16, void* g_out16, int pre_nblk,
+                    hipStream_t s);
+int launch_avgpool_bwd16(const float* dout, void* dx16, int N, int HW, int C, int dout_ld,
+                         hipStream_t s);
 // stem: BatchNorm apply + ReLU + max-pool without materialising the post-BN tensor, and its backward
 int launch_bn_relu_maxpool_fwd(const float* y, const float* stats, float* out,
                                unsigned char* argmax, int N, int H, int W, int C, hipStream_t s,
@@ -443,10 +456,27 @@ struct ConvF16Args {
                                   // enumerated grid [Ho][Wo] its INPUT: tap (kh', kw') of the
                                   // flipped filter reads x at ((h + pad - kh) / 2, (w + pad - kw) / 2),
                                   // kh = K-1-kh', when both differences are even (pad = forward pad)
+    // ---- 16-bit tensors end to end (the bf16 training mode since round 4): the raw result is
+    //      ROUNDED to 16 bits on its way out, y16 = round(acc + addend16), and everything derived
+    //      from it -- BatchNorm batch statistics (bn_partial) and the BatchNorm-backward
+    //      reductions (bwd_*16) -- is computed from the rounded values, so that BatchNorm is
+    //      exactly "fp32 BatchNorm of the stored 16-bit tensor" (what autocast-style training does)
+    cilrs_half* y16;              // 16-bit raw result instead of y32 (exactly one of the two)
+    const cilrs_half* addend16;   // optional 16-bit addend (either output type)
+    const cilrs_half* bwd_z16; const cilrs_half* bwd_y16;   // 16-bit forms of bwd_z / bwd_y
+    // ---- stride-2 data gradient by output-parity class (up2 == 2): the enumerated grid is the
+    //      sub-grid (h, w) = (2 i + ph, 2 j + pw) of the convolution's INPUT, its taps the
+    //      cls_ntaps filter taps of that parity (cls_tap[t] = flipped-tap index into w,
+    //      cls_dh/dw[t] = offset of the gathered dy pixel from (i, j)); all four classes in ONE
+    //      launch, tile ranges cls_tile_begin[0..4]
+    int cls_Ho[4], cls_Wo[4], cls_ph[4], cls_pw[4], cls_ntaps[4], cls_tile_begin[5];
+    int cls_tap[4][4], cls_dh[4][4], cls_dw[4][4];
 };
 // the same implicit GEMM with fp32 output: forward (w = 16-bit copy of the OHWI weights), data
 // gradient (w = transposed, tap-flipped 16-bit copy; stride 1: pad = K-1-pad_fwd; stride 2: up2)
 int launch_conv_f16_train(const ConvF16Args& a, hipStream_t s);
+int conv_f16_train_mtiles(const ConvF16Args& a);         // rows of the column partials it writes
+bool conv_f16_train_can_fuse_bwd(const ConvF16Args& a);  // BatchNorm-backward partials possible?
 // wT[ci][K-1-kh][K-1-kw][co] = (16-bit) w[co][kh][kw][ci]
 int launch_transpose_flip_f16(const float* w, void* wT, int Cout, int K, int Cin, int bf16,
                               hipStream_t s);

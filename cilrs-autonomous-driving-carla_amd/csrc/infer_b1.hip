@@ -116,7 +116,10 @@ __device__ __forceinline__ void grid_wait(int* sync, const int target, volatile 
                     int v;
                     asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)"
                                  : "=&v"(v) : "v"(sync + lane * 32) : "memory");
-                    ok = (v - target) >= 0;                   // wrap-safe
+                    // wrap-safe: the difference is formed in UNSIGNED arithmetic (signed overflow
+                    // is undefined, and hipcc folds `(v - target) >= 0` to `target <= v`, which
+                    // lets every wait pass on the launch that crosses INT_MAX)
+                    ok = (int)((unsigned)v - (unsigned)target) >= 0;
                 }
                 if (__all(ok)) break;
                 if (++spins > kSpinLimit) {
@@ -819,7 +822,7 @@ __global__ __launch_bounds__(kThreads) void infer_b1_kernel(const B1Launch a) {
             plan_clear(plan);
         }
         if (s > first) {
-            grid_wait(a.sync, base + (s - first) * per_shard, &fail, a.status);
+            grid_wait(a.sync, (int)((unsigned)base + (unsigned)((s - first) * per_shard)), &fail, a.status);
             failed = RFL(*reinterpret_cast<volatile int*>(&fail));
             if (defer && !failed) {
                 if (type == B1_CONV) plan_issue_b<0>(plan, cw, rsW, rsP);
@@ -850,7 +853,7 @@ __global__ __launch_bounds__(kThreads) void infer_b1_kernel(const B1Launch a) {
         }
     }
     if (blockIdx.x == 0 && tid == 0) {
-        __hip_atomic_store(a.sync + 8 * 32, base + (nstages - 1 - first) * per_shard, __ATOMIC_RELAXED,
+        __hip_atomic_store(a.sync + 8 * 32, (int)((unsigned)base + (unsigned)((nstages - 1 - first) * per_shard)), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
         if (*reinterpret_cast<volatile int*>(&fail)) {
             const float nan = __builtin_nanf("");

@@ -213,11 +213,13 @@ __global__ __launch_bounds__(256, (BM == 64 ? 2 : 2)) void conv_f16_kernel(const
     }
 
     if constexpr (TRAIN) {
-        // ---- training epilogue: BatchNorm column partials of the raw fp32 tile (rows >= M are
-        // exact zeros; fixed order => deterministic), then the tile through LDS to 16-byte fp32
-        // stores (+ fp32 addend) ----
+        // ---- training epilogue: BatchNorm column partials of the raw tile (rows >= M are exact
+        // zeros; fixed order => deterministic), then the tile through LDS to 16-byte stores:
+        // fp32 (y32) or ROUNDED to 16 bits (y16), + an fp32 or 16-bit addend.  With a 16-bit
+        // result every derived reduction is taken from the rounded values ----
         float* stage = reinterpret_cast<float*>(smem_raw);
         constexpr int SP = BN + 4;
+        const bool out16 = a.y16 != nullptr;
         if (a.bn_partial != nullptr) {
             float* red = stage;                           // [2][BN][2]
 #pragma unroll
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(256, (BM == 64 ? 2 : 2)) void conv_f16_kernel(const
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float v = acc[i][j][r];
+                        const float v = out16 ? (float)(T)acc[i][j][r] : acc[i][j][r];
                         s1 += v;
                         s2 = fmaf(v, v, s2);
                     }
@@ -271,6 +273,10 @@ __global__ __launch_bounds__(256, (BM == 64 ? 2 : 2)) void conv_f16_kernel(const
             rlo = *reinterpret_cast<const f32x4*>(a.bwd_stats + a.Cout + n0 + c8);
             rhi = *reinterpret_cast<const f32x4*>(a.bwd_stats + a.Cout + n0 + c8 + 4);
         }
+        const T* add16 = reinterpret_cast<const T*>(a.addend16);
+        const T* bz16 = reinterpret_cast<const T*>(a.bwd_z16);
+        const T* by16 = reinterpret_cast<const T*>(a.bwd_y16);
+        T* y16 = reinterpret_cast<T*>(a.y16);
 #pragma unroll
         for (int pass = 0; pass < BM / RPP; ++pass) {
             const int row = pass * RPP + rsub;
@@ -283,15 +289,58 @@ __global__ __launch_bounds__(256, (BM == 64 ? 2 : 2)) void conv_f16_kernel(const
                 lo += *reinterpret_cast<const f32x4*>(a.addend32 + o);
                 hi += *reinterpret_cast<const f32x4*>(a.addend32 + o + 4);
             }
-            *reinterpret_cast<f32x4*>(a.y32 + o) = lo;
-            *reinterpret_cast<f32x4*>(a.y32 + o + 4) = hi;
+            if (add16) {
+                const v8 av = *reinterpret_cast<const v8*>(add16 + o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    lo[e] += (float)av[e];
+                    hi[e] += (float)av[4 + e];
+                }
+            }
+            if (out16) {
+                v8 ov;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    ov[e] = (T)lo[e];
+                    ov[4 + e] = (T)hi[e];
+                }
+                *reinterpret_cast<v8*>(y16 + o) = ov;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {        // what was stored is what everything downstream sees
+                    lo[e] = (float)ov[e];
+                    hi[e] = (float)ov[4 + e];
+                }
+            } else {
+                *reinterpret_cast<f32x4*>(a.y32 + o) = lo;
+                *reinterpret_cast<f32x4*>(a.y32 + o + 4) = hi;
+            }
             if (bwd) {
-                const f32x4 ylo = *reinterpret_cast<const f32x4*>(a.bwd_y + o);
-                const f32x4 yhi = *reinterpret_cast<const f32x4*>(a.bwd_y + o + 4);
+                f32x4 ylo, yhi, zlo = {1.f, 1.f, 1.f, 1.f}, zhi = zlo;
+                if (by16) {
+                    const v8 yv = *reinterpret_cast<const v8*>(by16 + o);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        ylo[e] = (float)yv[e];
+                        yhi[e] = (float)yv[4 + e];
+                    }
+                    if (a.bwd_relu) {
+                        const v8 zv = *reinterpret_cast<const v8*>(bz16 + o);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            zlo[e] = (float)zv[e];
+                            zhi[e] = (float)zv[4 + e];
+                        }
+                    }
+                } else {
+                    ylo = *reinterpret_cast<const f32x4*>(a.bwd_y + o);
+                    yhi = *reinterpret_cast<const f32x4*>(a.bwd_y + o + 4);
+                    if (a.bwd_relu) {
+                        zlo = *reinterpret_cast<const f32x4*>(a.bwd_z + o);
+                        zhi = *reinterpret_cast<const f32x4*>(a.bwd_z + o + 4);
+                    }
+                }
                 f32x4 glo = lo, ghi = hi;
                 if (a.bwd_relu) {
-                    const f32x4 zlo = *reinterpret_cast<const f32x4*>(a.bwd_z + o);
-                    const f32x4 zhi = *reinterpret_cast<const f32x4*>(a.bwd_z + o + 4);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         glo[e] = zlo[e] > 0.f ? glo[e] : 0.f;
@@ -473,15 +522,23 @@ static int launch_conv_f16_train_t(const ConvF16Args& a, int M, hipStream_t s) {
     return 0;
 }
 
+// rows of the [2][Cout][M-tiles] column partials (bn_partial / bwd_partial) a launch writes
+int conv_f16_train_mtiles(const ConvF16Args& a) { return cdiv(a.N * a.Ho * a.Wo, 64); }
+// may the BatchNorm-backward reductions ride on this launch's epilogue?
+bool conv_f16_train_can_fuse_bwd(const ConvF16Args& a) { return a.up2 == 0; }
+
 int launch_conv_f16_train(const ConvF16Args& a, hipStream_t s) {
     CILRS_CHECK(a.Cin % HBK == 0 && a.Cout % 64 == 0 && a.K * a.K <= 16,
                 "conv_f16_train: Cin %% 64, Cout %% 64, <= 16 taps");
-    CILRS_CHECK(a.y32 != nullptr && ((uintptr_t)a.y32 & 15) == 0 &&
-                    ((uintptr_t)a.addend32 & 15) == 0,
-                "conv_f16_train: fp32 output missing / misaligned");
+    CILRS_CHECK((a.y32 != nullptr) != (a.y16 != nullptr) && ((uintptr_t)a.y32 & 15) == 0 &&
+                    ((uintptr_t)a.addend32 & 15) == 0 && ((uintptr_t)a.y16 & 15) == 0 &&
+                    ((uintptr_t)a.addend16 & 15) == 0 && !(a.addend32 && a.addend16),
+                "conv_f16_train: exactly one of the fp32 / 16-bit outputs, 16-byte aligned");
     CILRS_CHECK((size_t)a.N * a.H * a.W * a.Cin * 2 < (1ull << 32), "conv_f16_train: input too large");
     CILRS_CHECK(!a.up2 || a.stride == 2, "conv_f16_train: up2 is the stride-2 data gradient");
-    CILRS_CHECK(!a.bwd_partial || (a.bwd_y && a.bwd_stats && (a.bwd_z || !a.bwd_relu) && !a.up2),
+    CILRS_CHECK(!a.bwd_partial ||
+                    (a.bwd_stats && !a.up2 &&
+                     ((a.bwd_y && (a.bwd_z || !a.bwd_relu)) || (a.bwd_y16 && (a.bwd_z16 || !a.bwd_relu)))),
                 "conv_f16_train: BatchNorm-backward partials need y / stats (/ z), stride 1");
     const int M = a.N * a.Ho * a.Wo;
     return a.bf16 ? launch_conv_f16_train_t<__bf16>(a, M, s)

@@ -382,6 +382,9 @@ int zero_counters_once(cilrs_net* net, void* workspace, hipStream_t s) {
     if (net->cnt_zeroed_for == workspace) return 0;
     float* ws = reinterpret_cast<float*>(workspace);
     CILRS_HIP(hipMemsetAsync(ws + net->tile_cnt, 0, (kTileCounters + 2 * kBnSyncInts) * sizeof(int), s));
+    // the int32[4] status words start at zero in every workspace (a C-ABI caller brings its own,
+    // uninitialised one); afterwards the kernels only ever SET them: "since the caller last cleared"
+    CILRS_HIP(hipMemsetAsync(reinterpret_cast<char*>(workspace) + net->status_b, 0, 16, s));
     net->bn_sync[0].total = net->bn_sync[1].total = 0;
     net->cnt_zeroed_for = workspace;
     return 0;
@@ -589,45 +592,55 @@ cilrs_half* h16(float* ws, size_t off_floats) {
     return reinterpret_cast<cilrs_half*>(ws + off_floats);
 }
 
-// the same three operators on the bf16 matrix pipe (bf16 training mode); profile labels as above
+// the same three operators on the bf16 matrix pipe (bf16 training mode); profile labels as above.
+// Since round 4 the mode keeps every trunk tensor after the stem in bf16 (activations, raw
+// convolution outputs, gradients): the raw output y16 of convolution ci lives where the fp32 mode
+// keeps its y (same offset, half the bytes), the post-BatchNorm tensor in z16[ci].
+cilrs_half* y16_of(const cilrs_net* net, float* ws, int ci) { return h16(ws, net->cg[ci].y); }
+
 int conv_fwd16(cilrs_net* net, const ConvT& c, const ConvG& g, int ci, const cilrs_half* x16,
-               float* y, float* ws, hipStream_t s, int* bn_nblk) {
+               float* ws, hipStream_t s, int* bn_nblk) {
     ConvF16Args a;
     memset(&a, 0, sizeof(a));
-    a.x = x16; a.w = h16(ws, net->w16_all) + c.w; a.y32 = y;
+    a.x = x16; a.w = h16(ws, net->w16_all) + c.w; a.y16 = y16_of(net, ws, ci);
     a.bn_partial = ws + net->bn_partial;
     a.N = net->B; a.H = g.H; a.W = g.W; a.Cin = c.cin; a.Ho = g.Ho; a.Wo = g.Wo; a.Cout = c.cout;
     a.K = c.k; a.stride = c.stride; a.pad = c.pad; a.bf16 = 1;
-    *bn_nblk = cdiv(g.M, 64);
-    (void)ci;
+    *bn_nblk = conv_f16_train_mtiles(a);
     const double flops = 2.0 * g.M * c.cout * c.k * c.k * c.cin;
-    const double bytes = 2.0 * ((double)net->B * g.H * g.W * c.cin + (double)c.cout * c.k * c.k * c.cin) +
-                         4.0 * (double)g.M * c.cout;
+    const double bytes = 2.0 * ((double)net->B * g.H * g.W * c.cin + (double)c.cout * c.k * c.k * c.cin +
+                                (double)g.M * c.cout);
     RUN(net, std::string("conv_fwd.") + kGroupName[c.group], flops, bytes, s,
         launch_conv_f16_train(a, s));
     return 0;
 }
 
+// dx (16-bit, or fp32 when dx32 is given: the gradient handed to the fp32 stem) = dgrad(dy16)
+// (+ addend16); bn_of: the convolution whose BatchNorm-backward reductions ride on the epilogue
 int conv_dgrad16(cilrs_net* net, const ConvT& c, const ConvG& g, int ci, const cilrs_half* dy16,
-                 float* dx, const float* addend, float* ws, hipStream_t s,
-                 const ConvG* bn_of = nullptr, int* bwd_nblk = nullptr) {
+                 cilrs_half* dx16, float* dx32, const cilrs_half* addend16, float* ws,
+                 hipStream_t s, const ConvG* bn_of = nullptr, int* bwd_nblk = nullptr) {
     ConvF16Args a;
     memset(&a, 0, sizeof(a));
-    if (bwd_nblk) *bwd_nblk = 0;
-    if (bn_of && bwd_nblk && c.stride == 1) {     // the BatchNorm whose output gradient this is
-        a.bwd_z = ws + bn_of->z; a.bwd_y = ws + bn_of->y; a.bwd_stats = ws + bn_of->stats;
-        a.bwd_relu = 1; a.bwd_partial = ws + net->bn_partial;
-        *bwd_nblk = cdiv(net->B * g.H * g.W, 64);
-    }
-    a.x = dy16; a.w = h16(ws, net->wT16) + net->wT16_off[ci]; a.y32 = dx; a.addend32 = addend;
+    a.x = dy16; a.w = h16(ws, net->wT16) + net->wT16_off[ci];
+    if (dx32) a.y32 = dx32; else a.y16 = dx16;
+    a.addend16 = addend16;
     a.N = net->B; a.H = g.Ho; a.W = g.Wo; a.Cin = c.cout;      // gathered tensor = dy
     a.Ho = g.H; a.Wo = g.W; a.Cout = c.cin;                    // enumerated grid = dx
     a.K = c.k; a.bf16 = 1;
     if (c.stride == 1) { a.stride = 1; a.pad = c.k - 1 - c.pad; }
     else { a.stride = 2; a.pad = c.pad; a.up2 = 1; }
+    if (bwd_nblk) *bwd_nblk = 0;
+    if (bn_of && bwd_nblk && conv_f16_train_can_fuse_bwd(a)) {   // the BatchNorm whose output gradient this is
+        const int bi = (int)(bn_of - &net->cg[0]);
+        a.bwd_z16 = h16(ws, net->z16[bi]); a.bwd_y16 = y16_of(net, ws, bi);
+        a.bwd_stats = ws + bn_of->stats;
+        a.bwd_relu = 1; a.bwd_partial = ws + net->bn_partial;
+        *bwd_nblk = conv_f16_train_mtiles(a);
+    }
     const double flops = 2.0 * g.M * c.cout * c.k * c.k * c.cin;
     const double bytes = 2.0 * ((double)g.M * c.cout + (double)c.cout * c.k * c.k * c.cin) +
-                         4.0 * (double)net->B * g.H * g.W * c.cin;
+                         (dx32 ? 4.0 : 2.0) * (double)net->B * g.H * g.W * c.cin;
     RUN(net, std::string("conv_dgrad.") + kGroupName[c.group], flops, bytes, s,
         launch_conv_f16_train(a, s));
     return 0;
@@ -1081,19 +1094,26 @@ static int forward_from_x4(cilrs_net* net, const cilrs_buffers* bufs, const floa
     const float eps = 1e-5f, mom = 0.1f;
     const bool bf16t = train && net->bf16_train;      // trunk convolutions on the bf16 matrix pipe
 
-    auto bn = [&](int ci, const float* residual, int relu, int pre_nblk) -> int {
+    // (residual: fp32 tensor, or the bf16 identity in the bf16 training mode)
+    auto bn = [&](int ci, const void* residual_v, int relu, int pre_nblk) -> int {
+        const float* residual = reinterpret_cast<const float*>(residual_v);
         const ConvT& c = A.convs[ci];
         const ConvG& g = net->cg[ci];
         const BnT& b = A.bns[c.bn];
         const double bytes = 4.0 * g.M * c.cout * (residual ? 4.0 : 3.0);
-        if (train) {
+        if (bf16t) {         // 16-bit tensors: residual is the bf16 identity
+            RUN(net, std::string("bn_fwd.") + kGroupName[c.group], 0.0, bytes / 2.0, s,
+                launch_bn16_train_fwd(y16_of(net, ws, ci), g.M, c.cout, P + b.gamma, P + b.beta,
+                                      R + b.rm, R + b.rv,
+                                      reinterpret_cast<long long*>(bufs->bn_nbt) + c.bn, mom, eps,
+                                      residual, relu, ws + g.stats, ws + net->bn_partial,
+                                      h16(ws, net->z16[ci]), pre_nblk, s));
+        } else if (train) {
             RUN(net, std::string("bn_fwd.") + kGroupName[c.group], 0.0, bytes, s,
                 launch_bn_train_fwd(ws + g.y, g.M, c.cout, P + b.gamma, P + b.beta, R + b.rm,
                                     R + b.rv, reinterpret_cast<long long*>(bufs->bn_nbt) + c.bn,
                                     mom, eps, residual, relu, ws + g.stats, ws + net->bn_partial,
-                                    ws + g.z, pre_nblk, s,
-                                    bf16t ? (void*)h16(ws, net->z16[ci]) : nullptr,
-                                    bn_sync(net, ws, 0)));
+                                    ws + g.z, pre_nblk, s, nullptr, bn_sync(net, ws, 0)));
         } else {
             RUN(net, std::string("bn_fwd.") + kGroupName[c.group], 0.0, bytes, s,
                 launch_bn_eval_fwd(ws + g.y, g.M, c.cout, P + b.gamma, P + b.beta, R + b.rm,
@@ -1153,7 +1173,7 @@ static int forward_from_x4(cilrs_net* net, const cilrs_buffers* bufs, const floa
         for (const BlockT& blk : A.blocks) {
             const int chain[3] = {blk.conv1, blk.conv2, blk.conv3};
             const int nchain = blk.conv3 >= 0 ? 3 : 2;
-            const float* identity = cur;
+            const void* identity = bf16t ? (const void*)cur16 : (const void*)cur;
             const float* x = cur;
             const cilrs_half* x16 = cur16;
             for (int i = 0; i < nchain; ++i) {
@@ -1161,7 +1181,7 @@ static int forward_from_x4(cilrs_net* net, const cilrs_buffers* bufs, const floa
                 const ConvG& g = net->cg[chain[i]];
                 nb = 0;
                 if (bf16t) {
-                    if (conv_fwd16(net, c, g, chain[i], x16, ws + g.y, ws, s, &nb)) return 1;
+                    if (conv_fwd16(net, c, g, chain[i], x16, ws, s, &nb)) return 1;
                 } else {
                     if (conv_fwd(net, c, g, x, c.cin, P + c.w, ws + g.y, ws, s, &nb)) return 1;
                 }
@@ -1172,14 +1192,13 @@ static int forward_from_x4(cilrs_net* net, const cilrs_buffers* bufs, const floa
                     const ConvG& gd = net->cg[blk.down];
                     nb = 0;
                     if (bf16t) {
-                        if (conv_fwd16(net, cd, gd, blk.down, cur16, ws + gd.y, ws, s, &nb))
-                            return 1;
+                        if (conv_fwd16(net, cd, gd, blk.down, cur16, ws, s, &nb)) return 1;
                     } else {
                         if (conv_fwd(net, cd, gd, cur, cd.cin, P + cd.w, ws + gd.y, ws, s, &nb))
                             return 1;
                     }
                     if (bn(blk.down, nullptr, 0, nb)) return 1;
-                    identity = ws + gd.z;
+                    identity = bf16t ? (const void*)h16(ws, net->z16[blk.down]) : (const void*)(ws + gd.z);
                 } else if (i + 1 < nchain) {
                     if (bn(chain[i], nullptr, 1, nb)) return 1;
                 } else {
@@ -1190,6 +1209,12 @@ static int forward_from_x4(cilrs_net* net, const cilrs_buffers* bufs, const floa
             }
             cur = x;
             cur16 = x16;
+        }
+        if (bf16t) {         // features from the bf16 feature map
+            RUN(net, "heads_fwd", 0.0, 0.0, s,
+                launch_avgpool_f16(cur16, ws + net->combined, B, net->featHW, A.feat,
+                                   A.feat + 128, 1, s));
+            cur = nullptr;
         }
     } else {
         // eval: running statistics -> per-channel scale/shift (one launch for all 36 layers),
@@ -1752,6 +1777,7 @@ static int b1_launch(cilrs_net* net, const cilrs_buffers* bufs, const uint8_t* f
         if (b1_build(net, blocks)) return 1;
         net->b1_blocks = blocks;
     }
+    if (zero_counters_once(net, bufs->workspace, s)) return 1;     // (also: status words of a fresh workspace)
     if (eval_prep(net, bufs, s)) return 1;
     if (net->b1_ready_for != bufs->workspace) {
         CILRS_HIP(hipMemsetAsync(ws + net->b1_sync, 0, kB1SyncInts * sizeof(int), s));
@@ -1866,6 +1892,20 @@ int cilrs_net_b1_stage_us(cilrs_net* net, const cilrs_buffers* bufs, float* star
     return 0;
 }
 
+int cilrs_net_b1_set_epoch(cilrs_net* net, const cilrs_buffers* bufs, int value, void* stream) {
+    CILRS_CHECK(net && bufs && bufs->workspace, "b1_set_epoch: NULL");
+    CILRS_CHECK(net->b1_table != 0 && net->b1_ready_for == bufs->workspace,
+                "b1_set_epoch: no persistent launch on this workspace yet");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    CILRS_HIP(hipStreamSynchronize(s));
+    // the eight arrival shards and the epoch base are equal between launches: re-base all nine
+    std::vector<int> h(9 * 32, 0);
+    for (int i = 0; i < 9; ++i) h[i * 32] = value;
+    CILRS_HIP(hipMemcpy(reinterpret_cast<float*>(bufs->workspace) + net->b1_sync, h.data(),
+                        h.size() * sizeof(int), hipMemcpyHostToDevice));
+    return 0;
+}
+
 int cilrs_net_wino_convs(cilrs_net* net) { return net ? net->wino_table.n : 0; }
 
 int cilrs_net_b1_stages(cilrs_net* net) {
@@ -1971,9 +2011,14 @@ int cilrs_net_backward(cilrs_net* net, const cilrs_buffers* bufs, const float* d
             net->bwd_nblk_next = 0;
             if (backward_heads(net, bufs, dcontrols, dpred_speed, nullptr, s)) return 1;
             // d visual -> avgpool backward -> grad of the last block's output, in G[3]
-            RUN(net, "heads_bwd", 0.0, 0.0, s,
-                launch_avgpool_bwd(ws + net->dcombined, ws + net->G[3], B, net->featHW, A.feat,
-                                   A.feat + 128, s));
+            if (net->bf16_train)
+                RUN(net, "heads_bwd", 0.0, 0.0, s,
+                    launch_avgpool_bwd16(ws + net->dcombined, h16(ws, net->G16[3]), B, net->featHW,
+                                         A.feat, A.feat + 128, s));
+            else
+                RUN(net, "heads_bwd", 0.0, 0.0, s,
+                    launch_avgpool_bwd(ws + net->dcombined, ws + net->G[3], B, net->featHW, A.feat,
+                                       A.feat + 128, s));
             continue;
         }
         if (seg >= 1 && seg <= 4) {
@@ -1993,35 +2038,63 @@ int cilrs_net_backward(cilrs_net* net, const cilrs_buffers* bufs, const float* d
                 const float* xin;
                 if (bi == 0) xin = ws + net->pool;
                 else xin = ws + net->cg[last_conv(A.blocks[bi - 1])].z;
-                float* Gd = ws + net->G[3];
-                float* Gb = ws + net->G[1];
-                float* Gc = ws + net->G[2];
                 const std::string grp = kGroupName[c1.group];
                 // weight gradients run on side stream 0, concurrently with the data gradients
                 const bool bf16t = net->bf16_train;
-                // (x: the conv's input activation; x16: its bf16 shadow)
+                // gradient buffers by index: [3] d(block input / output), [1] identity-path
+                // gradient, [2] d(input of a main-branch convolution), ring slots = dy tensors;
+                // fp32 mode: ws + G[i]; bf16 mode: the bf16 buffer G16[i]
+                auto Gf = [&](int gi) { return ws + net->G[gi]; };
+                auto Gh = [&](int gi) { return h16(ws, net->G16[gi]); };
+                // (x: the conv's input activation; x16: its bf16 form)
                 auto wgrad_side = [&](const ConvT& c, const ConvG& g, const float* x,
                                       const cilrs_half* x16, int gi, float* dwdst) -> int {
                     if (gbuf_side_begin(net, s)) return 1;
                     if (bf16t) {
-                        if (conv_wgrad16(net, c, g, x16, h16(ws, net->G16[gi]), dwdst, ws,
-                                         side_or(net, s, 0))) return 1;
+                        if (conv_wgrad16(net, c, g, x16, Gh(gi), dwdst, ws, side_or(net, s, 0)))
+                            return 1;
                     } else {
-                        if (conv_wgrad(net, c, g, x, c.cin, ws + net->G[gi], dwdst, ws,
-                                       side_or(net, s, 0))) return 1;
+                        if (conv_wgrad(net, c, g, x, c.cin, Gf(gi), dwdst, ws, side_or(net, s, 0)))
+                            return 1;
                     }
                     return gbuf_side_end(net, gi);
                 };
-                // data gradient of conv `ci`: dy (ring slot gi) -> dx (+ addend)
-                auto dgrad = [&](int ci, int gi, float* dx, const float* addend,
-                                 const ConvG* bn_of, int* nbp) -> int {
+                // data gradient of conv `ci`: dy (buffer gi) -> buffer go (+ buffer gadd, -1: none);
+                // out32: the bf16 mode's last data gradient of the trunk, handed to the fp32 stem
+                auto dgrad = [&](int ci, int gi, int go, int gadd, const ConvG* bn_of, int* nbp,
+                                 bool out32 = false) -> int {
                     const ConvT& c = A.convs[ci];
                     const ConvG& g = net->cg[ci];
                     if (bf16t)
-                        return conv_dgrad16(net, c, g, ci, h16(ws, net->G16[gi]), dx, addend, ws, s,
-                                            bn_of, nbp);
-                    return conv_dgrad(net, c, g, ws + net->G[gi], P + c.w, dx, addend, ws, s, bn_of,
-                                      1, nbp);
+                        return conv_dgrad16(net, c, g, ci, Gh(gi), out32 ? nullptr : Gh(go),
+                                            out32 ? Gf(go) : nullptr, gadd >= 0 ? Gh(gadd) : nullptr,
+                                            ws, s, bn_of, nbp);
+                    return conv_dgrad(net, c, g, Gf(gi), P + c.w, Gf(go), gadd >= 0 ? Gf(gadd) : nullptr,
+                                      ws, s, bn_of, 1, nbp);
+                };
+                // BatchNorm backward of conv `ci`: dz (buffer gz) -> dy (buffer gdy), masked
+                // gradient -> buffer gg (-1: not needed)
+                auto bnb = [&](int ci, int gz, int relu, int gdy, int gg, int pre_nblk,
+                               double passes) -> int {
+                    const ConvT& c = A.convs[ci];
+                    const ConvG& g = net->cg[ci];
+                    const BnT& b = A.bns[c.bn];
+                    if (bf16t) {
+                        RUN(net, "bn_bwd." + grp, 0.0, 2.0 * g.M * c.cout * passes, s,
+                            launch_bn16_bwd(Gh(gz), relu ? h16(ws, net->z16[ci]) : nullptr,
+                                            y16_of(net, ws, ci), g.M, c.cout, P + b.gamma,
+                                            ws + g.stats, relu, Gp + b.gamma, Gp + b.beta,
+                                            ws + net->bn_coef, ws + net->bn_partial, Gh(gdy),
+                                            gg >= 0 ? Gh(gg) : nullptr, pre_nblk, s));
+                    } else {
+                        RUN(net, "bn_bwd." + grp, 0.0, 4.0 * g.M * c.cout * passes, s,
+                            launch_bn_bwd(Gf(gz), relu ? ws + g.z : nullptr, ws + g.y, g.M, c.cout,
+                                          P + b.gamma, ws + g.stats, relu, Gp + b.gamma,
+                                          Gp + b.beta, 0, ws + net->bn_coef, ws + net->bn_partial,
+                                          Gf(gdy), gg >= 0 ? Gf(gg) : nullptr, pre_nblk, s, nullptr,
+                                          bn_sync(net, ws, 1)));
+                    }
+                    return 0;
                 };
                 auto z16_of = [&](int ci) { return h16(ws, net->z16[ci]); };
                 const cilrs_half* xin16 =
@@ -2031,72 +2104,43 @@ int cilrs_net_backward(cilrs_net* net, const cilrs_buffers* bufs, const float* d
                     net->dy_pos = (net->dy_pos + 1) % dy_ring_depth();
                     return gi;
                 };
-                // 1. out = relu(bn_last(y_last) + identity): masked grad -> Gb, dy_last -> Ga
+                // 1. out = relu(bn_last(y_last) + identity): masked grad -> [1], dy_last -> ga
                 int ga = next_ring();
                 if (gbuf_acquire(net, s, ga) || gbuf_acquire(net, s, 1)) return 1;
-                float* Ga = ws + net->G[ga];
-                {
-                    const ConvT& cl = A.convs[chain[nchain - 1]];
-                    const ConvG& gl = net->cg[chain[nchain - 1]];
-                    const BnT& bl = A.bns[cl.bn];
-                    RUN(net, "bn_bwd." + grp, 0.0, 4.0 * gl.M * cl.cout * 8.0, s,
-                        launch_bn_bwd(Gd, ws + gl.z, ws + gl.y, gl.M, cl.cout, P + bl.gamma,
-                                      ws + gl.stats, 1, Gp + bl.gamma, Gp + bl.beta, 0,
-                                      ws + net->bn_coef, ws + net->bn_partial,
-                                      bf16t ? nullptr : Ga, Gb, net->bwd_nblk_next, s,
-                                      bf16t ? (void*)h16(ws, net->G16[ga]) : nullptr,
-                                      bn_sync(net, ws, 1)));
-                    net->bwd_nblk_next = 0;
-                }
-                // 2. walk the main branch backwards: dW_i (side), d(input of conv_i) -> Gc, then
+                if (bnb(chain[nchain - 1], 3, 1, ga, 1, net->bwd_nblk_next, 8.0)) return 1;
+                net->bwd_nblk_next = 0;
+                // 2. walk the main branch backwards: dW_i (side), d(input of conv_i) -> [2], then
                 //    a = relu(bn_{i-1}(y_{i-1})): dy_{i-1} -> the next dy buffer
                 for (int i = nchain - 1; i >= 1; --i) {
                     const ConvT& c = A.convs[chain[i]];
                     const ConvG& g = net->cg[chain[i]];
-                    const ConvT& cp = A.convs[chain[i - 1]];
                     const ConvG& gp = net->cg[chain[i - 1]];
-                    const BnT& bp = A.bns[cp.bn];
                     if (wgrad_side(c, g, ws + gp.z, z16_of(chain[i - 1]), ga, Gp + c.w)) return 1;
                     if (gbuf_acquire(net, s, 2)) return 1;
                     int nbp = 0;    // the previous BatchNorm's reductions ride on this dgrad's epilogue
-                    if (dgrad(chain[i], ga, Gc, nullptr, &gp, &nbp)) return 1;
+                    if (dgrad(chain[i], ga, 2, -1, &gp, &nbp)) return 1;
                     ga = next_ring();
                     if (gbuf_acquire(net, s, ga)) return 1;
-                    Ga = ws + net->G[ga];
-                    RUN(net, "bn_bwd." + grp, 0.0, 4.0 * gp.M * cp.cout * 7.0, s,
-                        launch_bn_bwd(Gc, ws + gp.z, ws + gp.y, gp.M, cp.cout, P + bp.gamma,
-                                      ws + gp.stats, 1, Gp + bp.gamma, Gp + bp.beta, 0,
-                                      ws + net->bn_coef, ws + net->bn_partial,
-                                      bf16t ? nullptr : Ga, nullptr, nbp, s,
-                                      bf16t ? (void*)h16(ws, net->G16[ga]) : nullptr,
-                                      bn_sync(net, ws, 1)));
+                    if (bnb(chain[i - 1], 2, 1, ga, -1, nbp, 7.0)) return 1;
                 }
                 // 3. dW1 (side)
                 if (wgrad_side(c1, g1, xin, xin16, ga, Gp + c1.w)) return 1;
                 if (blk.down < 0) {
-                    // 4. dx = dgrad(conv1) + identity grad (Gb) -> Gd
+                    // 4. dx = dgrad(conv1) + identity grad [1] -> [3]
                     // ... and carries the reductions of the previous block's last BatchNorm
                     const ConvG* prev = bi > 0 ? &net->cg[last_conv(A.blocks[bi - 1])] : nullptr;
-                    if (dgrad(blk.conv1, ga, Gd, Gb, prev, &net->bwd_nblk_next)) return 1;
+                    if (dgrad(blk.conv1, ga, 3, 1, prev, &net->bwd_nblk_next, bi == 0)) return 1;
                 } else {
                     const ConvT& cd = A.convs[blk.down];
                     const ConvG& gd = net->cg[blk.down];
-                    const BnT& bd = A.bns[cd.bn];
-                    if (dgrad(blk.conv1, ga, Gd, nullptr, nullptr, nullptr)) return 1;
+                    if (dgrad(blk.conv1, ga, 3, -1, nullptr, nullptr)) return 1;
                     // 5. identity = bn_d(conv_d(x)) (no ReLU): dy_d -> a dy buffer
                     const int gdn = next_ring();
                     if (gbuf_acquire(net, s, gdn)) return 1;
-                    float* Gdn = ws + net->G[gdn];
-                    RUN(net, "bn_bwd." + grp, 0.0, 4.0 * gd.M * cd.cout * 6.0, s,
-                        launch_bn_bwd(Gb, nullptr, ws + gd.y, gd.M, cd.cout, P + bd.gamma,
-                                      ws + gd.stats, 0, Gp + bd.gamma, Gp + bd.beta, 0,
-                                      ws + net->bn_coef, ws + net->bn_partial,
-                                      bf16t ? nullptr : Gdn, nullptr, 0, s,
-                                      bf16t ? (void*)h16(ws, net->G16[gdn]) : nullptr,
-                                      bn_sync(net, ws, 1)));
+                    if (bnb(blk.down, 1, 0, gdn, -1, 0, 6.0)) return 1;
                     if (wgrad_side(cd, gd, xin, xin16, gdn, Gp + cd.w)) return 1;
                     // 6. dx += dgrad(conv_d)
-                    if (dgrad(blk.down, gdn, Gd, Gd, nullptr, nullptr)) return 1;
+                    if (dgrad(blk.down, gdn, 3, 3, nullptr, nullptr, bi == 0)) return 1;
                 }
             }
             // the segment's weight gradients are complete when this call returns its work

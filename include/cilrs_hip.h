@@ -110,11 +110,16 @@ int cilrs_net_forward(cilrs_net* net, const cilrs_buffers* bufs, const float* im
                       int train, float dropout_p, uint64_t seed, float* controls,
                       float* pred_speed, void* stream);
 
-/* Byte offset, inside the workspace, of the plan's int32[4] status words.  Every forward entry
- * zeroes them first; word 0 becomes 1 when a `command` value lies outside {0..3} -- the case in
- * which the reference's torch.gather (autonomous_drive.py:397-398) raises.  The kernels then use
- * branch 0 so nothing faults; the host mirror reads the word at its next synchronisation
- * (Predictor: with the outputs; Trainer.losses() / validate()) and raises like torch does. */
+/* Byte offset, inside the workspace, of the plan's int32[4] status words.  The library zeroes them
+ * ONCE per workspace (the first entry point that sees a workspace pointer); after that the kernels
+ * only ever SET them, so a word means "since the caller last cleared it" (sticky): read them after
+ * synchronising the stream(s) the forwards ran on, and clear them with a 16-byte memset ordered
+ * after those forwards.  Word 0 becomes 1 when a `command` value lies outside {0..num_commands-1}
+ * -- the case in which the reference's torch.gather (autonomous_drive.py:397-398) raises; the
+ * kernels then use branch 0 so nothing faults.  Word 1: a grid barrier of the persistent
+ * single-frame launch gave up (outputs are NaN).  The host mirror reads the words at its next
+ * synchronisation (Predictor: with the outputs; Trainer.losses() / validate()) and raises like
+ * torch does. */
 size_t cilrs_net_status_offset(const cilrs_net* net);
 
 /* Inference between weight updates (the control loop, autonomous_drive.py:908-920, calls forward
@@ -203,7 +208,8 @@ int cilrs_net_forward_u8_graph(cilrs_net* net, const cilrs_buffers* bufs, const 
  * must be able to keep one workgroup per CU resident: a second persistent launch running at the
  * same time on the same device (another stream, another process) can stall both until the bounded
  * barrier spin gives up -- then status word 1 is set and the outputs are NaN.  Status word 0 is
- * written by every call (1: command outside 0..3, where the reference's torch.gather raises). */
+ * SET (never cleared: sticky, see cilrs_net_status_offset) by a call whose command lies outside
+ * 0..3, where the reference's torch.gather raises. */
 int cilrs_net_forward_u8_b1(cilrs_net* net, const cilrs_buffers* bufs, const uint8_t* frame,
                             const float* speed, const int64_t* command, float* controls,
                             float* pred_speed, void* stream);
@@ -237,6 +243,12 @@ int cilrs_net_wino_convs(cilrs_net* net);
 /* number of stages (= grid barriers + 1) of that launch; -1 before the first call, 0 if the plan
  * has no persistent path */
 int cilrs_net_b1_stages(cilrs_net* net);
+/* Re-base the launch's monotonic barrier counters (the eight arrival shards and the epoch word,
+ * which are equal between launches) to `value`, after synchronising `stream`.  The counters are
+ * compared wrap-safe (unsigned difference), so a long-running control loop never needs this; it
+ * exists so that a test can place them just below INT_MAX and watch the launch cross the wrap
+ * (tests/test_model_gpu.py), and as a maintenance hook. */
+int cilrs_net_b1_set_epoch(cilrs_net* net, const cilrs_buffers* bufs, int value, void* stream);
 /* diagnostics (library started with CILRS_B1_STAMPS=1): block 0's clock of the LAST persistent
  * launch -- start_us[i] = when stage i began (relative to stage 0), work_us[i] = how long block 0
  * worked in it before it entered the grid barrier.  Synchronous (one device->host copy). */

@@ -22,6 +22,7 @@ Tolerances (BASELINE.json north_star: "within 1e-4 fp32 on identical batches"):
   dropout         Config B as executed (p = 0.5): the masks the kernels used are regenerated
                   through the C-ABI (cilrs_dropout) and fed to the oracle functionally
 """
+import ctypes as C
 import json
 import os
 
@@ -1416,6 +1417,33 @@ def test_persistent_single_frame_kernel_vs_eager_and_oracle():
     for it in range(300):
         fi, cmd = it % len(frames), (it // 2) % 4
         assert pers.predict_controls(frames[fi], 7.0 + 21.0 * cmd + fi, cmd) == first[(fi, cmd)], it
+    # the monotonic barrier counters cross INT_MAX (`(v - target) >= 0` in signed
+    # arithmetic was folded to `target <= v`, and every wait of the launch that crosses the wrap
+    # passed at once): placed 2,000 below the wrap, each tick adds 37 stages x 32 arrivals = 1,184
+    # per shard, so the second tick crosses it -- every answer must still be its first answer
+    pers.stream.synchronize()
+    L.check(L.lib().cilrs_net_b1_set_epoch(pl.handle, C.byref(pl.bufs), 2**31 - 1 - 2000,
+                                           C.c_void_p(pers.stream.cuda_stream)))
+    for it in range(12):
+        fi, cmd = it % len(frames), (it // 2) % 4
+        assert pers.predict_controls(frames[fi], 7.0 + 21.0 * cmd + fi, cmd) == first[(fi, cmd)], it
+    # degraded mode: a barrier timeout is not an error of the frame -- the tick
+    # is served through the per-layer launches in the same process, with ONE warning, and the
+    # persistent launch is tried again DEGRADED_TICKS ticks later
+    import warnings
+    from cilrs_mi355 import predict as P
+    pers._inject_timeout = 1
+    with warnings.catch_warnings(record=True) as wlist:
+        warnings.simplefilter("always")
+        got = pers.predict_controls(frames[0], 7.0, 0)
+        again = pers.predict_controls(frames[0], 7.0, 0)
+    ref = eager.predict_controls(frames[0], 7.0, 0)
+    assert got == ref == again, (got, ref, again)                  # the per-layer path's answer
+    assert sum("grid barrier" in str(w.message) for w in wlist) == 1
+    assert pers.barrier_timeouts == 1 and pers.degraded_ticks_left == P.DEGRADED_TICKS - 1
+    pers.degraded_ticks_left = 0                                   # ... and back on the one launch
+    assert pers.predict_controls(frames[0], 7.0, 0) == first[(0, 0)]
+    pers.eng.check_status()                                        # nothing left behind
     # out-of-range command: status word 0, like the per-layer path
     dev = pers.eng.device
     fr = torch.from_numpy(frames[0])[None].to(dev)

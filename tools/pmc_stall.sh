@@ -19,7 +19,9 @@ for sub in "abc":
     agg = {}
     for r in csv.DictReader(open(fs[0])):
         n = r["Kernel_Name"]
-        fam = ("igemm128" if "conv_igemm_kernel<128" in n else "igemm64" if "conv_igemm_kernel<64" in n
+        fam = ("wino_q" if "conv_wino_q_kernel" in n else "wino" if "conv_wino_kernel" in n
+               else "wino_wgrad" if "wino_wgrad_kernel" in n
+               else "igemm128" if "conv_igemm_kernel<128" in n else "igemm64" if "conv_igemm_kernel<64" in n
                else "wgrad128" if "conv_wgrad_kernel<128" in n else "wgrad64" if "conv_wgrad_kernel<64" in n else None)
         if fam is None: continue
         agg.setdefault((fam, r["Dispatch_Id"]), {})[r["Counter_Name"]] = float(r["Counter_Value"])
