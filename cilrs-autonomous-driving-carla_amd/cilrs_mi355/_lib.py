@@ -106,6 +106,10 @@ SIGNATURES = {
     "cilrs_conv2d_dgrad_16": (i32, [vp, vp, vp, vp] + [i32] * 9 + [vp, vp]),
     "cilrs_conv2d_wgrad_16_scratch_floats": (sz, [i32] * 8),
     "cilrs_conv2d_wgrad_16": (i32, [vp, vp, vp, vp] + [i32] * 9 + [vp, vp]),
+    "cilrs_conv2d_train_16": (i32, [vp] * 9 + [i32, vp] + [i32] * 12 + [vp, vp]),
+    "cilrs_bn16_train_fwd": (i32, [vp, i32, i32, vp, vp, vp, vp, vp, C.c_float, C.c_float, vp, i32,
+                                   vp, vp, vp, i32, vp]),
+    "cilrs_bn16_bwd": (i32, [vp, vp, vp, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, vp]),
     "cilrs_conv2d_wino_scratch_floats": (sz, [i32, i32]),
     "cilrs_conv2d_wino_fwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
     "cilrs_wino_filter_transform": (i32, [vp, vp, i32, i32, i32, vp]),

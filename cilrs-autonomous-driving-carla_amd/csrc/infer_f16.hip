@@ -522,8 +522,8 @@ static int launch_conv_f16_train_t(const ConvF16Args& a, int M, hipStream_t s) {
     return 0;
 }
 
-// rows of the [2][Cout][M-tiles] column partials (bn_partial / bwd_partial) a launch writes
-int conv_f16_train_mtiles(const ConvF16Args& a) { return cdiv(a.N * a.Ho * a.Wo, 64); }
+// (conv_f16_train_mtiles -- rows of the column partials a launch writes -- lives with the tile plan
+//  in conv16.hip)
 // may the BatchNorm-backward reductions ride on this launch's epilogue?
 bool conv_f16_train_can_fuse_bwd(const ConvF16Args& a) { return a.up2 == 0; }
 
@@ -541,6 +541,9 @@ int launch_conv_f16_train(const ConvF16Args& a, hipStream_t s) {
                      ((a.bwd_y && (a.bwd_z || !a.bwd_relu)) || (a.bwd_y16 && (a.bwd_z16 || !a.bwd_relu)))),
                 "conv_f16_train: BatchNorm-backward partials need y / stats (/ z), stride 1");
     const int M = a.N * a.Ho * a.Wo;
+    // large layers: persistent 128-row tiles (conv16.hip); -1 = this launch stays on 64x64
+    const int rc = launch_conv16_large(a, s);
+    if (rc >= 0) return rc;
     return a.bf16 ? launch_conv_f16_train_t<__bf16>(a, M, s)
                   : launch_conv_f16_train_t<_Float16>(a, M, s);
 }

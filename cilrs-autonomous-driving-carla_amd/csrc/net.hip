@@ -2533,6 +2533,53 @@ int cilrs_conv2d_wgrad_16(const float* x, const float* dy, float* dw, float* scr
         make_wgrad16(x16, dy16, dw, scratch32, N, H, W, Cin, Cout, K, stride, pad, bf16), s);
 }
 
+// ---- the bf16 training mode's operators on 16-bit tensors (round 4: activations and gradients
+//      live in bf16 end to end), op by op ----
+int cilrs_conv2d_train_16(const void* x16, const void* w16, void* y16, float* y32,
+                          const void* addend16, float* bn_partial, const void* bwd_z16,
+                          const void* bwd_y16, const float* bwd_stats, int bwd_relu,
+                          float* bwd_partial, int N, int H, int W, int Cin, int Ho, int Wo, int Cout,
+                          int K, int stride, int pad, int up2, int bf16, int* partial_rows,
+                          void* stream) {
+    CILRS_CHECK(x16 && w16 && (y16 || y32), "conv2d_train_16: NULL argument");
+    ConvF16Args a;
+    memset(&a, 0, sizeof(a));
+    a.x = reinterpret_cast<const cilrs_half*>(x16);
+    a.w = reinterpret_cast<const cilrs_half*>(w16);
+    a.y16 = reinterpret_cast<cilrs_half*>(y16);
+    a.y32 = y16 ? nullptr : y32;
+    a.addend16 = reinterpret_cast<const cilrs_half*>(addend16);
+    a.bn_partial = bn_partial;
+    a.bwd_z16 = reinterpret_cast<const cilrs_half*>(bwd_z16);
+    a.bwd_y16 = reinterpret_cast<const cilrs_half*>(bwd_y16);
+    a.bwd_stats = bwd_stats; a.bwd_relu = bwd_relu; a.bwd_partial = bwd_partial;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
+    a.K = K; a.stride = stride; a.pad = pad; a.up2 = up2; a.bf16 = bf16;
+    CILRS_CHECK(!bwd_partial || conv_f16_train_can_fuse_bwd(a),
+                "conv2d_train_16: BatchNorm-backward partials are not available for this launch");
+    if (partial_rows) *partial_rows = conv_f16_train_mtiles(a);
+    return launch_conv_f16_train(a, reinterpret_cast<hipStream_t>(stream));
+}
+
+int cilrs_bn16_train_fwd(const void* y16, int M, int C, const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, int64_t* nbt, float momentum,
+                         float eps, const void* residual16, int relu, float* stats, float* partial,
+                         void* z16, int pre_rows, void* stream) {
+    CILRS_CHECK(y16 && gamma && beta && stats && partial, "bn16_train_fwd: NULL argument");
+    return launch_bn16_train_fwd(y16, M, C, gamma, beta, running_mean, running_var,
+                                 reinterpret_cast<long long*>(nbt), momentum, eps, residual16, relu,
+                                 stats, partial, z16, pre_rows, reinterpret_cast<hipStream_t>(stream));
+}
+
+int cilrs_bn16_bwd(const void* dz16, const void* z16, const void* y16, int M, int C,
+                   const float* gamma, const float* stats, int relu, float* dgamma, float* dbeta,
+                   float* coef3c, float* partial, void* dy16, void* g_out16, int pre_rows,
+                   void* stream) {
+    CILRS_CHECK(gamma && stats && dgamma && dbeta && coef3c && partial, "bn16_bwd: NULL argument");
+    return launch_bn16_bwd(dz16, z16, y16, M, C, gamma, stats, relu, dgamma, dbeta, coef3c, partial,
+                           dy16, g_out16, pre_rows, reinterpret_cast<hipStream_t>(stream));
+}
+
 // Winograd F(2x2,3x3) forms of the two operators above (3x3 / stride 1 / pad 1): filter transform
 // + fused convolution.  scratch: cilrs_conv2d_wino_scratch_floats(Cin, Cout) floats.
 size_t cilrs_conv2d_wino_scratch_floats(int Cin, int Cout) { return wino_weight_floats(Cout, Cin); }

@@ -384,6 +384,39 @@ size_t cilrs_conv2d_wgrad_16_scratch_floats(int N, int H, int W, int Cin, int Co
 int cilrs_conv2d_wgrad_16(const float* x, const float* dy, float* dw, float* scratch32, int N,
                           int H, int W, int Cin, int Cout, int K, int stride, int pad, int bf16,
                           void* scratch16, void* stream);
+
+/* The bf16 training mode's operators on 16-bit tensors (round 4: every trunk tensor after the stem
+ * -- activations, raw convolution outputs, gradients -- is stored in bf16; fp32 accumulation,
+ * statistics and coefficients).  No reference counterpart (the reference trains in fp32,
+ * notebook/notebook.ipynb:549-555); defined by oracle/bf16_emulation.py.
+ *
+ * cilrs_conv2d_train_16: implicit-GEMM convolution of the 16-bit NHWC tensor x16 [N][H][W][Cin] with
+ * 16-bit weights w16 [Cout][K][K][Cin] over the output grid [N][Ho][Wo] (forward: the OHWI weights
+ * rounded; data gradient: x16 = dy, w16 = the transposed, tap-flipped weights, pad = K-1-pad_fwd,
+ * or up2 = 1 with stride 2 for the gradient of a stride-2 convolution).  Result = acc (+ addend16),
+ * ROUNDED to 16 bits into y16, or fp32 into y32 when y16 is NULL.  bn_partial (optional):
+ * BatchNorm batch statistics of the stored result as column partials [2][Cout][rows];
+ * bwd_partial (optional, with bwd_z16 / bwd_y16 / bwd_stats): BatchNorm-backward reductions of the
+ * produced gradient, g = result * (z > 0 if bwd_relu), partials of g and g * xhat.  *partial_rows
+ * receives the number of partial rows (the launch's 64- or 128-row tiles). */
+int cilrs_conv2d_train_16(const void* x16, const void* w16, void* y16, float* y32,
+                          const void* addend16, float* bn_partial, const void* bwd_z16,
+                          const void* bwd_y16, const float* bwd_stats, int bwd_relu,
+                          float* bwd_partial, int N, int H, int W, int Cin, int Ho, int Wo, int Cout,
+                          int K, int stride, int pad, int up2, int bf16, int* partial_rows,
+                          void* stream);
+/* BatchNorm2d (training) on bf16 NHWC tensors: statistics of y16 (from `partial` when pre_rows > 0:
+ * rows written by cilrs_conv2d_train_16), z16 = round(relu?(bn(y16) (+ residual16))); and its
+ * backward: dy16 = round(BatchNorm backward of g = dz16 * (z16 > 0 if relu)), g_out16 = g.
+ * Semantics of cilrs_bn_train_fwd / cilrs_bn_bwd otherwise (nn.BatchNorm2d, nb:440-477). */
+int cilrs_bn16_train_fwd(const void* y16, int M, int C, const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, int64_t* nbt, float momentum,
+                         float eps, const void* residual16, int relu, float* stats, float* partial,
+                         void* z16, int pre_rows, void* stream);
+int cilrs_bn16_bwd(const void* dz16, const void* z16, const void* y16, int M, int C,
+                   const float* gamma, const float* stats, int relu, float* dgamma, float* dbeta,
+                   float* coef3c, float* partial, void* dy16, void* g_out16, int pre_rows,
+                   void* stream);
 /* nn.BatchNorm2d training forward (+ optional residual add, ReLU); stats: 4*C floats out */
 /* The same 3x3 / stride 1 / pad 1 convolution (nn.Conv2d(C, K, 3, 1, 1, bias=False) of
  * torchvision's BasicBlock: conv1 of every non-first block and every conv2) and its data gradient

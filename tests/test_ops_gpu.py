@@ -593,6 +593,150 @@ def test_conv16_fwd_dgrad_wgrad(case, bf16):
     assert (dw.cpu().double() - want).abs().max() <= 5e-5 * float(want.abs().max())
 
 
+# ---- the bf16 training mode's operators on 16-bit tensors (round 4) ------------------------------
+CONV16T_CASES = [
+    # N, H, W, Cin, Cout, k, s, p                 tile the launch plan picks on a 256-CU device
+    (2, 22, 50, 64, 64, 3, 1, 1),                 # 64x64 (small layer)
+    (16, 44, 100, 64, 128, 3, 1, 1),              # 128x128, nine K-tiles per tile
+    (16, 44, 100, 64, 64, 1, 1, 0),               # 128x64, ONE K-tile per tile (all epilogue)
+    (33, 44, 50, 256, 128, 1, 1, 0),              # 128x128, ragged last tile (M % 128 = 24)
+    (64, 44, 100, 64, 128, 3, 2, 1),              # 128x128, stride 2
+    (5, 6, 13, 256, 256, 3, 1, 1),                # 64x64, 36 K-tiles
+]
+
+
+def _bf(t):
+    return t.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("case", CONV16T_CASES)
+def test_conv16_train_ops_on_16bit_tensors(case):
+    """cilrs_conv2d_train_16 (both tile families): bf16 in, result ROUNDED to bf16 (+ bf16 addend),
+    BatchNorm statistics and BatchNorm-backward reductions taken from the STORED values.  Against
+    torch's fp32 CPU convolution of the same bf16 operands: one bf16 ulp (2^-8 relative; the two
+    fp32 sums differ in order, which can move a result across a rounding boundary); the column
+    partials against sums of what the kernel stored: 1e-4."""
+    L = _lib()
+    lib = L.lib()
+    N, H, W, Cin, Cout, k, s, p = case
+    g = torch.Generator().manual_seed(23)
+    x = _bf(torch.randn(N, Cin, H, W, generator=g))
+    w = _bf(torch.randn(Cout, Cin, k, k, generator=g) / (k * k * Cin) ** 0.5)
+    torch.set_num_threads(16)
+    ref = F.conv2d(x.float(), w.float(), None, s, p)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    M = N * Ho * Wo
+    ref = ref.permute(0, 2, 3, 1).reshape(M, Cout)
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+    wd = w.permute(0, 2, 3, 1).contiguous().cuda()
+    rows = C.c_int(0)
+
+    def run(y16, y32, add, part, bz, by, bstats, brelu, bpart):
+        L.check(lib.cilrs_conv2d_train_16(L.ptr(xd), L.ptr(wd), L.ptr(y16), L.ptr(y32), L.ptr(add),
+                                          L.ptr(part), L.ptr(bz), L.ptr(by), L.ptr(bstats), brelu,
+                                          L.ptr(bpart), N, H, W, Cin, Ho, Wo, Cout, k, s, p, 0, 1,
+                                          C.byref(rows), stream()))
+        torch.cuda.synchronize()
+
+    ulp = 2.0 ** -8
+    # (1) forward form: rounded result + BatchNorm statistics of the stored tensor
+    y = torch.full((M, Cout), float("nan"), dtype=torch.bfloat16, device="cuda")
+    part = torch.full((2 * Cout * ((M + 63) // 64),), float("nan"), device="cuda")
+    run(y, None, None, part, None, None, None, 0, None)
+    got = y.float().cpu()
+    assert torch.isfinite(got).all()
+    assert ((got - ref).abs() <= ulp * ref.abs() + 1e-6 * float(ref.abs().max())).all()
+    nr = rows.value
+    assert nr in ((M + 63) // 64, (M + 127) // 128)
+    pp = part[:2 * Cout * nr].cpu().double().view(2, Cout, nr).sum(-1)
+    s1, s2 = got.double().sum(0), (got.double() ** 2).sum(0)
+    assert (pp[0] - s1).abs().max() <= 1e-4 * max(1.0, float(s1.abs().max()))
+    assert (pp[1] - s2).abs().max() <= 1e-4 * float(s2.max())
+    # (2) data-gradient form: + bf16 addend, BatchNorm-backward reductions of the stored gradient
+    add = _bf(torch.randn(M, Cout, generator=g))
+    bz = _bf(torch.randn(M, Cout, generator=g))
+    by = _bf(torch.randn(M, Cout, generator=g))
+    bstats = torch.cat([torch.randn(Cout, generator=g) * 0.1, torch.rand(Cout, generator=g) + 0.5])
+    bpart = torch.full((2 * Cout * ((M + 63) // 64),), float("nan"), device="cuda")
+    y.fill_(float("nan"))
+    run(y, None, add.cuda(), None, bz.cuda(), by.cuda(), bstats.cuda(), 1, bpart)
+    got = y.float().cpu()
+    want = ref + add.float()
+    assert ((got - want).abs() <= ulp * want.abs() + 1e-6 * float(want.abs().max())).all()
+    gm = torch.where(bz.float() > 0, got, torch.zeros_like(got)).double()
+    xh = (by.double() - bstats[:Cout].double()) * bstats[Cout:].double()
+    nr = rows.value
+    pp = bpart[:2 * Cout * nr].cpu().double().view(2, Cout, nr).sum(-1)
+    t1, t2 = gm.sum(0), (gm * xh).sum(0)
+    scale = max(1.0, float(gm.abs().sum(0).max()))
+    assert (pp[0] - t1).abs().max() <= 1e-4 * scale
+    assert (pp[1] - t2).abs().max() <= 1e-4 * max(1.0, float((gm * xh).abs().sum(0).max()))
+    # (3) fp32 result with a bf16 addend (the gradient handed to the fp32 stem)
+    y32 = torch.full((M, Cout), float("nan"), device="cuda")
+    run(None, y32, add.cuda(), None, None, None, None, 0, None)
+    assert (y32.cpu() - want).abs().max() <= 5e-5 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("M,Cch", [(2 * 22 * 50, 64), (8 * 11 * 25, 128), (3 * 6 * 13, 256),
+                                   (77, 2048), (16 * 44 * 100, 256)])
+def test_bn16_fwd_bwd_on_bf16_tensors(M, Cch):
+    """BatchNorm2d (training) on bf16 NHWC tensors against torch's fp32 BatchNorm of the SAME bf16
+    tensor: outputs / input gradients within one bf16 ulp, statistics / parameter gradients 1e-4,
+    running statistics 1e-5, the residual path's masked gradient exact."""
+    L = _lib()
+    lib = L.lib()
+    g = torch.Generator().manual_seed(7)
+    y = _bf(torch.randn(M, Cch, generator=g) * 1.5 + 0.3)
+    res = _bf(torch.randn(M, Cch, generator=g))
+    gamma = torch.rand(Cch, generator=g) + 0.5
+    beta = torch.randn(Cch, generator=g) * 0.2
+    rm0, rv0 = torch.randn(Cch, generator=g) * 0.1, torch.rand(Cch, generator=g) + 0.5
+    dz = _bf(torch.randn(M, Cch, generator=g))
+    yf = y.float().requires_grad_(True)
+    gp, bp = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm, rv = rm0.clone(), rv0.clone()
+    t = F.batch_norm(yf.t().reshape(1, Cch, M, 1), rm, rv, gp, bp, True, 0.1, 1e-5)
+    t = t.reshape(Cch, M).t()
+    zref = F.relu(t + res.float())
+    zq = _bf(zref).float()
+    # backward as the mode defines it: the mask comes from the STORED z, dz is a stored bf16 tensor
+    gmask = torch.where(zq > 0, dz.float(), torch.zeros(()))
+    (t * gmask.detach()).sum().backward()
+    yd, resd, dzd = y.cuda(), res.cuda(), dz.cuda()
+    stats = torch.full((4 * Cch,), float("nan"), device="cuda")
+    partial = torch.empty(lib.cilrs_bn_partial_floats(Cch), device="cuda")
+    z = torch.full((M, Cch), float("nan"), dtype=torch.bfloat16, device="cuda")
+    rmd, rvd = rm0.cuda(), rv0.cuda()
+    nbt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    gd, bd = gamma.cuda(), beta.cuda()
+    L.check(lib.cilrs_bn16_train_fwd(L.ptr(yd), M, Cch, L.ptr(gd), L.ptr(bd), L.ptr(rmd), L.ptr(rvd),
+                                     L.ptr(nbt), 0.1, 1e-5, L.ptr(resd), 1, L.ptr(stats),
+                                     L.ptr(partial), L.ptr(z), 0, stream()))
+    torch.cuda.synchronize()
+    ulp = 2.0 ** -8
+    zg = z.float().cpu()
+    assert ((zg - zref.detach()).abs() <= ulp * zref.detach().abs() + 1e-5).all()   # (fp32 BatchNorm sums of 70,400 rows differ in order)
+    assert (rmd.cpu() - rm).abs().max() <= 1e-5 and (rvd.cpu() - rv).abs().max() <= 1e-5
+    assert int(nbt) == 1
+    # backward on the kernel's own z (the mask must be the stored one)
+    dy = torch.full((M, Cch), float("nan"), dtype=torch.bfloat16, device="cuda")
+    gout = torch.full((M, Cch), float("nan"), dtype=torch.bfloat16, device="cuda")
+    dgam, dbet = torch.empty(Cch, device="cuda"), torch.empty(Cch, device="cuda")
+    coef = torch.empty(3 * Cch, device="cuda")
+    L.check(lib.cilrs_bn16_bwd(L.ptr(dzd), L.ptr(z), L.ptr(yd), M, Cch, L.ptr(gd), L.ptr(stats), 1,
+                               L.ptr(dgam), L.ptr(dbet), L.ptr(coef), L.ptr(partial), L.ptr(dy),
+                               L.ptr(gout), 0, stream()))
+    torch.cuda.synchronize()
+    same_mask = (zg > 0) == (zq > 0)
+    assert same_mask.float().mean() > 0.9999       # (an element at rounding distance from zero may flip)
+    if bool(same_mask.all()):
+        assert torch.equal(gout.float().cpu(), gmask)
+        want = yf.grad
+        assert ((dy.float().cpu() - want).abs() <= ulp * want.abs() + 1e-5 * float(want.abs().max())).all()
+        assert (dgam.cpu() - gp.grad).abs().max() <= 1e-4 * max(1.0, float(gp.grad.abs().max()))
+        assert (dbet.cpu() - bp.grad).abs().max() <= 1e-4 * max(1.0, float(bp.grad.abs().max()))
+
+
 # ---- Winograd F(2x2, 3x3) forms of the 3x3 / stride 1 / pad 1 convolution ------------------------
 WINO_CASES = [
     (3, 22, 50, 64, 64),       # layer1
