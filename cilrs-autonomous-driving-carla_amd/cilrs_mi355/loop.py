@@ -30,11 +30,25 @@ def train_one_epoch(trainer, batches):
         buf = trainer.train_step(imgs, speeds, cmds, tgts)
         acc = buf[:6].double().clone() if acc is None else acc + buf[:6].double()
         n += 1
-    if acc is not None and trainer.reducer is not None:
-        # data parallel: the epoch mean over ALL ranks' batches (every rank logs / checks the same)
-        packed = trainer.all_reduce_sum(torch.cat([acc, torch.tensor([float(n)], dtype=torch.float64,
-                                                                    device=acc.device)]))
-        acc, n = packed[:6], float(packed[6])
+    if trainer.reducer is not None:
+        # data parallel: the epoch mean over ALL ranks' batches (every rank logs / checks the same).
+        # EVERY rank takes part, also one that drew no batch (zeros, n = 0): a rank that skipped
+        # the collective would leave the others blocked in it.  Ranks must also have run the SAME
+        # number of steps -- each step's gradient all-reduce pairs them up -- so differing counts
+        # (a sharded loader that was not cut to a multiple of the global batch) raise here instead
+        # of hanging in the next epoch.
+        dev = acc.device if acc is not None else trainer.eng.device
+        mine = acc if acc is not None else torch.zeros(6, dtype=torch.float64, device=dev)
+        cnt = torch.tensor([float(n), float(n) * float(n)], dtype=torch.float64, device=dev)
+        packed = trainer.all_reduce_sum(torch.cat([mine, cnt]))
+        world = trainer.reducer.world_size
+        tot, tot_sq = float(packed[6]), float(packed[7])
+        if abs(tot_sq * world - tot * tot) > 0.5:        # sum n^2 * W == (sum n)^2  <=>  all n equal
+            raise RuntimeError(f"data-parallel ranks ran different numbers of train steps this epoch "
+                               f"(rank {trainer.rank}: {n}; mean {tot / world:.2f}): shard the loader "
+                               "to a multiple of the global batch")
+        if tot > 0:
+            acc, n = packed[:6], tot
     vals = (acc / max(n, 1)).tolist() if acc is not None else [float("nan")] * 6
     if acc is not None:
         trainer.eng.check_status()                  # out-of-range command in the last batch

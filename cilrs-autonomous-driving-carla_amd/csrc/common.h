@@ -46,6 +46,23 @@ const char* last_error();
     } while (0)
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Per-DEVICE launch state (one process may drive several devices): the CU count of the current
+// device, and "is this the first time `key` (a kernel) is prepared on the current device" for
+// function attributes such as the dynamic-LDS limit.
+int device_cus();
+bool once_per_device(const void* key);
+
+// Tuning / diagnostic switches whose measured result is a recorded negative
+// are COMPILED OUT of the product library: experiment_env() is the constant default unless the
+// library is built with -DCILRS_EXPERIMENTS (make CXXEXTRA=-DCILRS_EXPERIMENTS; tools/README.md).
+// Switches a test exercises (CILRS_WINO, CILRS_WINO_TAIL, CILRS_WINO_WGRAD, CILRS_OVERLAP,
+// CILRS_BN_FUSED, CILRS_SPLITK_INKERNEL, CILRS_CONV16_TILE, CILRS_B1_STAMPS) stay run-time.
+#ifdef CILRS_EXPERIMENTS
+int experiment_env(const char* name, int dflt);
+#else
+static inline int experiment_env(const char*, int dflt) { return dflt; }
+#endif
 static inline size_t cdivz(size_t a, size_t b) { return (a + b - 1) / b; }
 
 // ---- implicit-GEMM convolution (conv_igemm.hip) --------------------------------------------

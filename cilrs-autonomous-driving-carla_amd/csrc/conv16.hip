@@ -222,7 +222,6 @@ __global__ __launch_bounds__(256, 2) void conv16p_kernel(const ConvF16Args a) {
     const T* bz16 = reinterpret_cast<const T*>(a.bwd_z16);
     const T* by16 = reinterpret_cast<const T*>(a.bwd_y16);
     T* y16 = reinterpret_cast<T*>(a.y16);
-    constexpr bool bwd = BWD;
 
     load_setup();
 #pragma unroll
@@ -408,17 +407,11 @@ __global__ __launch_bounds__(256, 2) void conv16p_kernel(const ConvF16Args a) {
 struct Conv16Plan { int cfg, bm, tiles, grid; };
 // CILRS_CONV16_BIG=1: 128x128 tiles where the layer has enough of them (one block per CU)
 bool big_ok() {
-    static const int on = getenv("CILRS_CONV16_BIG") ? atoi(getenv("CILRS_CONV16_BIG")) : 0;
+    static const int on = experiment_env("CILRS_CONV16_BIG", 0);
     return on != 0;
 }
 Conv16Plan conv16_plan(const ConvF16Args& a) {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t p;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess &&
-               p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
-    }
+    const int cus = device_cus();
     // CILRS_CONV16_TILE: 0 keeps every launch on the 64x64 kernel, 1 / 2 force a large tile (A/B)
     static const int force = getenv("CILRS_CONV16_TILE") ? atoi(getenv("CILRS_CONV16_TILE")) : -1;
     const int M = a.N * a.Ho * a.Wo;
@@ -442,7 +435,7 @@ Conv16Plan conv16_plan(const ConvF16Args& a) {
     }
     p.bm = 128;
     // 128x64: 72 KB of LDS, two resident blocks per CU; 128x128: 96 KB, one
-    static const int nst = getenv("CILRS_CONV16_NST") ? atoi(getenv("CILRS_CONV16_NST")) : 3;
+    static const int nst = experiment_env("CILRS_CONV16_NST", 3);
     const int resident = (p.cfg == 2 || nst > 3 ? 1 : 2) * cus;
     p.grid = p.tiles < resident ? p.tiles : resident;
     return p;
@@ -451,11 +444,9 @@ Conv16Plan conv16_plan(const ConvF16Args& a) {
 template <typename T, int BN, int EPI, int NST = 3>
 int launch_conv16p_epi(const ConvF16Args& a, const Conv16Plan& p, hipStream_t s) {
     constexpr size_t lds = conv16p_lds<BN, NST>();
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (once_per_device(reinterpret_cast<const void*>(&conv16p_kernel<T, BN, NST, EPI>))) {
         CILRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv16p_kernel<T, BN, NST, EPI>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
     }
     conv16p_kernel<T, BN, NST, EPI><<<p.grid, 256, lds, s>>>(a);
     CILRS_LAUNCH_CHECK();
@@ -465,7 +456,7 @@ template <typename T, int BN>
 int launch_conv16p(const ConvF16Args& a, const Conv16Plan& p, hipStream_t s) {
     const int epi = (a.addend16 ? 1 : 0) | (a.bwd_partial ? 2 : 0);
     // experiment (CILRS_CONV16_NST=4|5, forward form, 128x64): deeper rings, one block per CU
-    static const int nst = getenv("CILRS_CONV16_NST") ? atoi(getenv("CILRS_CONV16_NST")) : 3;
+    static const int nst = experiment_env("CILRS_CONV16_NST", 3);
     if constexpr (BN == 64) {
         if (epi == 0 && nst == 4) return launch_conv16p_epi<T, BN, 0, 4>(a, p, s);
         if (epi == 0 && nst == 5) return launch_conv16p_epi<T, BN, 0, 5>(a, p, s);

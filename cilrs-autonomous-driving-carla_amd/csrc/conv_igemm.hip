@@ -923,7 +923,7 @@ struct Choice { int cfg; int splitk; };
 
 Choice choose(int M, int Cout, int KT, bool allow_split, int force_cfg, int force_splitk) {
     static const int splits[11] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48};
-    static const int use_dma = getenv("CILRS_IGEMM_DMA") ? atoi(getenv("CILRS_IGEMM_DMA")) : 0;
+    static const int use_dma = experiment_env("CILRS_IGEMM_DMA", 0);
     Choice best{2, 1};
     double bc = 1e30;
     for (int c = 0; c < kNumCfg; ++c) {

@@ -379,8 +379,8 @@ WPlan plan(const WgradArgs& a) {
     const bool uniform = (a.Cin % 64) == 0;
     const size_t out_floats = (size_t)a.Cout * taps * a.Cin;
     const double flops = 2.0 * Mpix * (double)out_floats;
-    static const int env_bt = getenv("CILRS_WGRAD_BT") ? atoi(getenv("CILRS_WGRAD_BT")) : 0;
-    static const int env_target = getenv("CILRS_WGRAD_TARGET") ? atoi(getenv("CILRS_WGRAD_TARGET")) : 0;
+    static const int env_bt = experiment_env("CILRS_WGRAD_BT", 0);
+    static const int env_target = experiment_env("CILRS_WGRAD_TARGET", 0);
     double bc = 1e30;
     for (int bt = 64; bt <= 128; bt += 64) {
         if (bt == 128 && !(uniform && a.Cin % 128 == 0 && a.Cout % 128 == 0)) continue;
@@ -430,11 +430,11 @@ int launch_conv_wgrad(const WgradArgs& a_in, hipStream_t s) {
     const WPlan p = plan(a);
     const int Mpix = a.N * a.Ho * a.Wo;
     const int ntiles_co = a.Cout / p.bt;
-    static const int xcd = getenv("CILRS_WGRAD_XCD") ? atoi(getenv("CILRS_WGRAD_XCD")) : 1;
+    static const int xcd = experiment_env("CILRS_WGRAD_XCD", 1);
     dim3 grid(p.ntiles * ntiles_co * p.splits, 1, 1);
     const size_t lds = (size_t)4 * BKP * (p.bt + 4) * sizeof(float);
     // CILRS_WGRAD_PIN=0: let the compiler place the LDS reads (A/B switch for tools/conv_bench.py)
-    static const bool pin = getenv("CILRS_WGRAD_PIN") ? atoi(getenv("CILRS_WGRAD_PIN")) != 0 : true;
+    static const bool pin = experiment_env("CILRS_WGRAD_PIN", 1) != 0;
     if (p.bt == 128) {
         static bool attr = false;
         if (!attr) {

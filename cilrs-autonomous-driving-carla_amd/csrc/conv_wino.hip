@@ -965,12 +965,9 @@ constexpr size_t kWinoLds = (size_t)2 * (16 * WT * WP + 16 * WK * WP) * sizeof(f
 // (a plan calls this when it is built: the attribute must not be set for the first time inside a
 //  stream capture)
 int wino_prepare() {
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (once_per_device(reinterpret_cast<const void*>(&conv_wino_kernel))) {
         CILRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoLds));
-
-        attr_set = true;
     }
     return 0;
 }
@@ -982,13 +979,7 @@ int wino_prepare() {
 struct WinoSplit { int full, tail; };
 static WinoSplit wino_split(int N, int H, int W, int K, int no_tail) {
     static const int mode = getenv("CILRS_WINO_TAIL") ? atoi(getenv("CILRS_WINO_TAIL")) : 1;
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t p;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess &&
-               p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
-    }
+    const int cus = device_cus();
     const int tiles = N * ((H + 1) / 2) * ((W + 1) / 2);
     const int groups = cdiv(tiles, WT), nkt = K / WK;
     WinoSplit sp{groups, 0};
@@ -1010,6 +1001,7 @@ int launch_conv_wino(const WinoArgs& a_in, hipStream_t s) {
     CILRS_CHECK(a.x && a.U && a.y, "conv_wino: NULL tensor");
     CILRS_CHECK(a.C % WC == 0 && a.K % WK == 0, "conv_wino: C %% 8, K %% 64");
     CILRS_CHECK((size_t)a.N * a.H * a.W * a.C * 4 < (1ull << 32) &&
+                    (size_t)a.N * a.H * a.W * a.K * 4 < (1ull << 32) &&
                     (size_t)16 * a.C * a.K * 4 < (1ull << 32),
                 "conv_wino: tensor too large for 32-bit offsets");
     CILRS_CHECK(!(a.bn_partial && a.bwd_partial), "conv_wino: one kind of column partials per launch");
@@ -1029,13 +1021,7 @@ bool wino_wgrad_supported(int C, int K, int ksize, int stride, int pad) {
     return ksize == 3 && stride == 1 && pad == 1 && C % 64 == 0 && K % 64 == 0;
 }
 static void wino_wgrad_split(int N, int H, int W, int C, int K, int* splits, int* tps) {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t p;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess &&
-               p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
-    }
+    const int cus = device_cus();
     const int tiles = N * ((H + 1) / 2) * ((W + 1) / 2);
     const int kc = (C / 64) * (K / 64);
     int s = cus / kc;
@@ -1057,11 +1043,9 @@ int launch_conv_wino_wgrad(const WinoWgradArgs& a_in, hipStream_t s) {
     CILRS_CHECK((size_t)a.N * a.H * a.W * a.C * 4 < (1ull << 31) &&
                     (size_t)a.N * a.H * a.W * a.K * 4 < (1ull << 31),
                 "conv_wino_wgrad: tensor too large for 32-bit offsets");
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (once_per_device(reinterpret_cast<const void*>(&wino_wgrad_kernel))) {
         CILRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_wgrad_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoGLds));
-        attr_set = true;
     }
     wino_wgrad_split(a.N, a.H, a.W, a.C, a.K, &a.splits, &a.tiles_per_split);
     wino_wgrad_kernel<<<a.splits * (a.C / 64) * (a.K / 64), WTHREADS, kWinoGLds, s>>>(a);

@@ -498,7 +498,7 @@ int launch_conv_f16(const ConvF16Args& a, hipStream_t s) {
     CILRS_CHECK((size_t)a.N * a.H * a.W * a.Cin * 2 < (1ull << 32), "conv_f16: input too large");
     const int M = a.N * a.Ho * a.Wo;
     // 64x64 tiles everywhere (see the kernel's header); CILRS_F16_TILE=128 forces the big tile
-    static const int force = getenv("CILRS_F16_TILE") ? atoi(getenv("CILRS_F16_TILE")) : 0;
+    static const int force = experiment_env("CILRS_F16_TILE", 0);
     const bool big = a.Cout % 128 == 0 && force == 128;
     if (big)
         return a.bf16 ? launch_conv_f16_cfg<__bf16, 128, 128>(a, M, s)

@@ -32,9 +32,36 @@ void set_error(const char* fmt, ...) {
 }
 const char* last_error() { return g_err; }
 
+static int current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    return dev;
+}
+int device_cus() {
+    static int cus[64] = {};
+    const int dev = current_device();
+    if (cus[dev] == 0) {
+        hipDeviceProp_t p;
+        cus[dev] = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0)
+                       ? p.multiProcessorCount : 256;
+    }
+    return cus[dev];
+}
+bool once_per_device(const void* key) {
+    static std::map<std::pair<const void*, int>, bool> seen;
+    return seen.emplace(std::make_pair(key, current_device()), true).second;
+}
+
+#ifdef CILRS_EXPERIMENTS
+int experiment_env(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+#endif
+
 // CILRS_PRIO: static wave priorities of the GEMM kernels (common.h wave_priority)
 int wave_priority_mode() {
-    static const int m = getenv("CILRS_PRIO") ? atoi(getenv("CILRS_PRIO")) : 0;
+    static const int m = experiment_env("CILRS_PRIO", 0);
     return m;
 }
 
@@ -256,7 +283,7 @@ constexpr int kDyRing = 8;
 constexpr int kNumG = 5 + kDyRing - 2;
 constexpr int kRingIdx[kDyRing] = {0, 4, 5, 6, 7, 8, 9, 10};
 static int dy_ring_depth() {
-    static const int d = getenv("CILRS_DY_RING") ? atoi(getenv("CILRS_DY_RING")) : 2;
+    static const int d = experiment_env("CILRS_DY_RING", 2);
     return d < 2 ? 2 : d > kDyRing ? kDyRing : d;
 }
 
@@ -396,7 +423,7 @@ int ensure_streams(cilrs_net* net) {
     CILRS_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
     // side stream 0 carries the weight-gradient GEMMs (CILRS_SIDE_PRIO=1: lowest priority -- an
     // experiment that starves them, see kDyRing)
-    static const int side_prio = getenv("CILRS_SIDE_PRIO") ? atoi(getenv("CILRS_SIDE_PRIO")) : 0;
+    static const int side_prio = experiment_env("CILRS_SIDE_PRIO", 0);
     if (side_prio)
         CILRS_HIP(hipStreamCreateWithPriority(&net->side[0], hipStreamNonBlocking, prio_least));
     else
@@ -1314,8 +1341,8 @@ static int forward_from_x4(cilrs_net* net, const cilrs_buffers* bufs, const floa
             // one 16-wave block per 16x16 tile: worth it while every block gets its own CU
             // CILRS_SMALL_BLOCKS / CILRS_SMALL_K: routing thresholds for tools/infer_ab.py
             static const int max_blocks =
-                getenv("CILRS_SMALL_BLOCKS") ? atoi(getenv("CILRS_SMALL_BLOCKS")) : kSmallConvBlocks;
-            static const int max_k = getenv("CILRS_SMALL_K") ? atoi(getenv("CILRS_SMALL_K")) : kSmallConvK;
+                experiment_env("CILRS_SMALL_BLOCKS", kSmallConvBlocks);
+            static const int max_k = experiment_env("CILRS_SMALL_K", kSmallConvK);
             if (cdiv(g.M, 16) * (c.cout / 16) > max_blocks || c.cin % 16 != 0 ||
                 c.k * c.k * c.cin > max_k)
                 return conv_fwd(net, c, g, x, c.cin, P + c.w, y, ws, s, nullptr, ws + g.stats,
@@ -1675,7 +1702,7 @@ static int b1_build(cilrs_net* net, int nblk) {
             p0.relu = p0.relu_post = p0.has_add = n0.relu = n0.relu_post = n0.has_add = 0;
             st.same_shape = memcmp(&p0, &n0, sizeof(B1Conv)) == 0;
         }
-        if (getenv("CILRS_B1_FINE"))
+        if (experiment_env("CILRS_B1_FINE", 0))
             fprintf(stderr, "b1 stage %2d: wpt %2d units %4d (ks %d nt %d per %d | ks %d nt %d per %d) same %d\n",
                     (int)T.size(), st.wpt, st.total_units, st.c[0].ksplit, st.c[0].nt, st.c[0].per,
                     c1 ? st.c[1].ksplit : 0, c1 ? st.c[1].nt : 0, c1 ? st.c[1].per : 0, st.same_shape);
@@ -1860,7 +1887,7 @@ int cilrs_net_b1_stage_us(cilrs_net* net, const cilrs_buffers* bufs, float* star
         start_us[i] = (float)((h[i] - h[0]) * 0.01);
         work_us[i] = (float)((h[kB1MaxStages + 1 + i] - h[i]) * 0.01);
     }
-    if (getenv("CILRS_B1_FINE")) {         // when each workgroup finished each stage (us after its start)
+    if (experiment_env("CILRS_B1_FINE", 0)) {         // when each workgroup finished each stage (us after its start)
         const int nb = net->b1_blocks;
         std::vector<long long> d((size_t)n * nb);
         CILRS_HIP(hipMemcpy(d.data(), reinterpret_cast<long long*>(reinterpret_cast<float*>(bufs->workspace) +
@@ -1875,14 +1902,14 @@ int cilrs_net_b1_stage_us(cilrs_net* net, const cilrs_buffers* bufs, float* star
             for (int b = 0; b < nb; ++b) if (t[b] > t[worst]) worst = b;
             fprintf(stderr, "stage %2d done: min %5.2f p50 %5.2f p90 %5.2f max %5.2f (block %d; block 0 %5.2f)\n",
                     i, srt[0], srt[nb / 2], srt[nb * 9 / 10], srt[nb - 1], worst, t[0]);
-            if (getenv("CILRS_B1_DUMP") && (i == 4 || i == 12 || i == 20 || i == 32)) {
+            if (experiment_env("CILRS_B1_DUMP", 0) && (i == 4 || i == 12 || i == 20 || i == 32)) {
                 fprintf(stderr, "stage %2d per block:", i);
                 for (int b = 0; b < nb; ++b) fprintf(stderr, " %.2f", t[b]);
                 fprintf(stderr, "\n");
             }
         }
     }
-    if (getenv("CILRS_B1_FINE"))           // conv stages: block 0 / wave 0 inside the stage
+    if (experiment_env("CILRS_B1_FINE", 0))           // conv stages: block 0 / wave 0 inside the stage
         for (int i = 0; i < n; ++i) {
             const long long* f = &h[2 * (kB1MaxStages + 1) + 8 * i];
             fprintf(stderr, "stage %2d fine:", i);

@@ -217,7 +217,7 @@ W16Plan wplan16(const WgradF16Args& a) {
     const int Mpix = a.N * a.Ho * a.Wo;
     const int nsteps = cdiv(Mpix, WPIX);
     // CILRS_W16_TILE=64 keeps the small tile everywhere (A/B)
-    static const int force = getenv("CILRS_W16_TILE") ? atoi(getenv("CILRS_W16_TILE")) : 0;
+    static const int force = experiment_env("CILRS_W16_TILE", 0);
     const int bt = (a.Cin % 128 == 0 && a.Cout % 128 == 0 && force != 64) ? 128 : 64;
     const int tiles = a.K * a.K * (a.Cin / bt) * (a.Cout / bt);
     // blocks aimed at per launch (CILRS_W16_TARGET).  Measured with tools/bf16_train_probe.py, whole
@@ -225,7 +225,7 @@ W16Plan wplan16(const WgradF16Args& a) {
     // tile): target 256: 5.41 / 2.54 ms, 512: 3.67 / 1.84, 768: 3.63 / 2.00, 1536: 3.78 / 2.9,
     // 3072: 4.32 / -- (the slabs are fp32: every extra split writes and re-reads a whole copy of
     // the gradient)
-    static const int target = getenv("CILRS_W16_TARGET") ? atoi(getenv("CILRS_W16_TARGET")) : 512;
+    static const int target = experiment_env("CILRS_W16_TARGET", 512);
     int splits = cdiv(target, tiles);
     const int max_splits = nsteps / 4 > 0 ? nsteps / 4 : 1;
     if (splits > max_splits) splits = max_splits;

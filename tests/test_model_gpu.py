@@ -140,6 +140,13 @@ OUTLIER_FLOOR_1 = 8
 
 
 def _close_params(mine, want, lr, steps):
+    """Post-Adam parameters, model level.  NOTE (VERDICT r3 "weak" 2): SURVEY.md section 7 asks for
+    "post-Adam params abs 1e-6"; at model level that cannot hold for ANY two fp32 implementations
+    (Adam's first step is lr * sign(g), and a gradient within fp32 noise of zero flips sign), so it
+    is replaced by this statistical gate -- a hard 2.2 * lr * steps bound on every element and, after
+    one step, at most 2x the measured fraction of elements beyond 2e-5 -- plus the ELEMENT-WISE 1e-6
+    check of the optimiser itself on identical gradients
+    (tests/test_ops_gpu.py::test_adam_step_matches_torch_adam, five steps, moments included)."""
     err = (mine - want).abs()
     assert float(err.max()) <= 2.2 * lr * steps + 1e-6
     if steps == 1:
@@ -623,8 +630,17 @@ def _grad_budget_check(tag, named_oracle_params, gv, g64, coef, cos_floor=1e-5, 
     realisations: gradients of the same step from OTHER fp32 CPU realisations (thread count,
     memory format).  With them the per-tensor floor is what those realisations show -- the worst
     of their errors against float64 and of their distances from each other: every tensor within
-    4x of it, at most 5 % of the tensors above 2x -- instead of the constant 5e-3 (round 2's gate flipped on a tensor at 5.57e-3 after a legal change of
-    summation order; measured here the CPU realisations themselves sit up to ~1e-2 apart)."""
+    2x of it, at most max(3, 5 %) of the tensors above 1.5x -- instead of the constant 5e-3 (round
+    2's gate flipped on a tensor at 5.57e-3 after a legal change of summation order; measured here
+    the CPU realisations themselves sit up to ~1e-2 apart).
+    History of the multiplier (VERDICT r3 "weak" 1): it was 2x, failed once in round 3
+    (gpurun_out/r3_splitk_test.log:115: visual_encoder.7.2.bn1.weight at 2.4x of a floor built
+    from TWO CPU realisations, 1.5e-4 / 6.7e-4 apart) and was widened to 4x in the same diff that
+    added two more realisations.  The realisations were the fix, not the multiplier: with four of
+    them the worst engine / floor ratio is 0.73 (Config A) / 0.71 (Config B), nothing above 1.0
+    has been seen since (profiles/r03_b128_gradient_floor.log, profiles/r04_gpu_tests.log), so
+    the gate is back at 2x and the 4x head-room -- slack a wiring bug in one tensor could have
+    hidden in -- is gone."""
     dot = n1 = n2 = 0.0
     cdot = cn1 = 0.0
     worst_gpu = worst_cpu = 0.0
@@ -647,7 +663,7 @@ def _grad_budget_check(tag, named_oracle_params, gv, g64, coef, cos_floor=1e-5, 
             #  but equally legal summation order lands one ulp away, 6.6e-8)
             floor = max(max(e_alt), spread, 2.5e-7)
             ratios.append((e_gpu / max(floor, 1e-12), n))
-            assert e_gpu <= max(4.0 * e_cpu, 4.0 * floor), (tag, n, e_gpu, e_alt, spread)
+            assert e_gpu <= 2.0 * floor, (tag, n, e_gpu, e_alt, spread)
         gmax = max(float(ref64.abs().max()), 1e-12)
         m_gpu = float((mine - ref64).abs().max())
         m_cpu = float((p.grad.double() - ref64).abs().max())
@@ -673,11 +689,11 @@ def _grad_budget_check(tag, named_oracle_params, gv, g64, coef, cos_floor=1e-5, 
     if ratios:
         # Against the measured floor (worst CPU realisation error / spread of that tensor): a
         # tensor may sit above it -- which tensors a handful of flipped ReLU decisions land on is
-        # random in every implementation -- but only a few may, and none far (4x, asserted above)
+        # random in every implementation -- but only a few may, and none far (2x, asserted above)
         ratios.sort(reverse=True)
-        above = sum(1 for r, _ in ratios if r > 2.0)
+        above = sum(1 for r, _ in ratios if r > 1.5)
         print(f"{tag}: engine error / measured CPU floor per tensor: worst {ratios[0][0]:.2f} "
-              f"({ratios[0][1]}), median {ratios[len(ratios) // 2][0]:.2f}, {above} of {len(ratios)} above 2x")
+              f"({ratios[0][1]}), median {ratios[len(ratios) // 2][0]:.2f}, {above} of {len(ratios)} above 1.5x")
         assert above <= max(3, len(ratios) // 20), (tag, ratios[:5])
     cpu_omc = 1.0 - cdot / (cn1 ** 0.5 * n2 ** 0.5)
     assert 1.0 - cos <= max(4.0 * cpu_omc, cos_floor), (tag, 1.0 - cos, cpu_omc)
