@@ -40,6 +40,7 @@ import torch.distributed as dist  # noqa: E402
 TRAIN_GFLOP_PER_FRAME = 8.39      # BASELINE.md section 2 (fwd 2.798 x 3)
 PEAK_F32_MATRIX_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBS = 8000.0
+PEAK_F16_TFLOPS = 2500.0            # dense fp16 / bf16 matrix peak (not the 2:1-sparsity figure)
 
 
 def synthetic_batch(batch, seed, device):
@@ -198,6 +199,8 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-infer", action="store_true")
+    ap.add_argument("--no-loader", action="store_true",
+                    help="skip the input-pipeline leg (JPEG decode pool -> augmentation -> train step)")
     ap.add_argument("--force-dp", action="store_true",
                     help="use the bucketed all-reduce path even with one rank (rehearsal)")
     ap.add_argument("--rehearse", action="store_true",
@@ -389,6 +392,27 @@ def main():
             "flops_basis": "direct convolution",
             "winograd_convs": nwino,
         }
+        # What that fraction is NOT: occupancy of the matrix pipe.  A Winograd launch issues 2.25x
+        # fewer multiplies than the direct-convolution flops it is credited with, so the share of
+        # the fp32 MFMA issue rate the family actually uses is lower: frac_issued prices the
+        # Winograd launches' flops at 1 / 2.25.  mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES over all
+        # SIMD-cycles per kernel from the committed rocprofv3 PMC pass (tools/pmc_mfma.sh ->
+        # profiles/r04_mfma_util.json), not measured in this run.
+        if dom is igemm and nwino == 24:
+            # the 24 Winograd convolutions of the reference network: the stride-1 3x3 layers of
+            # layers 1-3 (6 + 7 + 11), forward and data gradient each
+            B_ = args.batch
+            wino_flops = 2.0 * sum(n * 2.0 * B_ * h * w * c * 9 * c
+                                   for n, h, w, c in ((6, 22, 50, 64), (7, 11, 25, 128), (11, 6, 13, 256)))
+            wino_flops *= args.profile_steps
+            issued = dom["flops"] - wino_flops * (1.0 - 1.0 / 2.25)
+            out["roofline"]["frac_issued"] = round(issued / max(dom["ms"], 1e-9) / 1e9 / PEAK_F32_MATRIX_TFLOPS, 4)
+        mpath = os.path.join(ROOT, "profiles", "r04_mfma_util.json")
+        if os.path.exists(mpath):
+            mj = json.load(open(mpath))
+            out["roofline"]["mfma_busy"] = {k: v.get("mfma_busy_frac") for k, v in mj.items()
+                                            if isinstance(v, dict) and "mfma_busy_frac" in v}
+            out["roofline"]["mfma_busy_from"] = "profiles/r04_mfma_util.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES; tools/pmc_mfma.sh)"
         # HBM traffic per launch of that kernel family is NOT measured in this run: it is the
         # committed summary of separate rocprofv3 PMC passes over this same command (FETCH_SIZE
         # doubled, WRITE_SIZE as is -- MI355X_MICROARCH.md, HBM section; tools/pmc_traffic.sh)
@@ -525,6 +549,31 @@ def main():
                 eng.run_forward_u8(u320, s320, c320, half=half)
             torch.cuda.synchronize(dev)
             out[key]["one_batch_of_320_frames_per_s"] = round(320 * 5 / (time.perf_counter() - t0), 1)
+            if half:
+                # roofline of the config-5 leg: trunk convolutions on the fp16 matrix pipe (33 of
+                # the 36: 2.70 of the 2.798 GFLOP per frame; stem + heads fp32) against the dense
+                # fp16 peak, and the algorithmic bytes (16-bit activations in + out per layer,
+                # folded weights once per batch) against HBM
+                pl64 = eng.plan(64, 88, 200)
+                pl64.profile_reset(); pl64.profile(True)
+                for _ in range(3):
+                    eng.run_forward_u8(u64[0], spd64, cmd64, half=True)
+                torch.cuda.synchronize(dev)
+                t64 = pl64.profile_table(); pl64.profile(False)
+                cv = [v for k, v in t64.items() if k.startswith("conv_fwd.") and k != "conv_fwd.stem"]
+                cms, cfl, cby = (sum(v[q] for v in cv) / 3 for q in ("ms", "flops", "bytes"))
+                out[key]["roofline"] = {
+                    "kernel": "conv_f16_kernel<fp16> (35 launches per 64-frame forward)", "bound": "mfma",
+                    "achieved": round(320 * TRAIN_GFLOP_PER_FRAME / 3.0 / 1e3 / best, 1),
+                    "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(320 * TRAIN_GFLOP_PER_FRAME / 3.0 / 1e3 / best / PEAK_F16_TFLOPS, 4),
+                    "basis": "whole-forward flops of 320 frames / wall time of the five concurrent lanes",
+                    "conv_kernels_serial": {"ms_per_64_frames": round(cms, 4),
+                                            "tflops": round(cfl / max(cms, 1e-9) / 1e9, 1),
+                                            "gbs": round(cby / max(cms, 1e-9) / 1e6, 1),
+                                            "frac_mfma": round(cfl / max(cms, 1e-9) / 1e9 / PEAK_F16_TFLOPS, 4),
+                                            "frac_hbm": round(cby / max(cms, 1e-9) / 1e6 / PEAK_HBM_GBS, 4)},
+                    "profile": "profiles/r04_infer_f16/kernel_stats.csv (rocprofv3 --kernel-trace --stats)"}
         # device-side breakdown of one B=1 forward (eager launches, hipEvent per kernel)
         pl1 = trainer.eng.plan(1, 88, 200)
         pl1.profile_reset()
@@ -550,6 +599,25 @@ def main():
                      f"bound by 37 dependent grid-wide hand-offs ({dev_us / 38:.1f} us per stage: "
                      "barrier ~2 us + the stage's dependent memory-side round trips), not by either"}
         model.train()
+
+        # ---- the input pipeline in front of the step (the reference's 2-worker
+        # JPEG DataLoader, notebook.ipynb cell lines 387-431, would starve this consumer): decode
+        # pool -> pinned batch -> H2D -> fused augmentation kernel, alone and feeding the train
+        # step, on synthetic 200x88 JPEGs the leg writes itself (bounded: 2,048 frames)
+        if not args.no_loader:
+            try:
+                import importlib.util
+                spec = importlib.util.spec_from_file_location(
+                    "loader_bench", os.path.join(ROOT, "tools", "loader_bench.py"))
+                lb = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(lb)
+                from cilrs_mi355.hostinfo import usable_cores
+                res = lb.measure(frames=2048, batch=args.batch, workers=usable_cores(),
+                                 trainer=trainer, log=log)
+                out["loader"] = res
+                out["loader_frames_per_s"] = res["loader_frames_per_s"]
+            except Exception as e:                      # the headline must not depend on this leg
+                out["loader"] = {"error": repr(e)}
 
         # ---- BASELINE configs[3] on this GPU's share: ResNet-50 variant, 176x400 frames, trunk
         # on the bf16 matrix pipe (BatchNorm folded), batched inference at 64 frames per call.

@@ -45,6 +45,22 @@ constexpr int WC = 8;              // input channels per reduction chunk
 constexpr int WP = 8;              // LDS row pitch (floats) of the V / U images: no pad -- TWO stages fit
                                    // (2 x 64 KB) and a fragment read covers 512 contiguous bytes
 constexpr int WTHREADS = 512;
+// Position (floats) of (row r, channel pair p) inside one transform position's plane of ROWS rows x
+// 8 channels: TWO sub-planes of ROWS x 16 bytes, pair p in sub-plane p >> 1.  An operand fragment
+// read is one ds_read_b64 per lane, lane = (row l & 15, pair l >> 4); ds_read_b64 resolves bank
+// conflicts per 32-lane half over 64 banks (= 256 bytes), and a half -- 16 rows x pairs {0, 1} or
+// {2, 3} -- then reads 256 CONTIGUOUS bytes.  With plain 32-byte rows (rounds 3's layout) a half
+// read 16-byte pieces 32 bytes apart, lanes l and l + 8 on the same banks: every fragment read
+// took two LDS passes (rocprofv3: SQ_LDS_BANK_CONFLICT 80 per GPU cycle on this kernel, 0 on every
+// other one -- profiles/r04_pmc/).  The writers (8-byte V stores, 16-byte U stores) land in 256- /
+// 512-byte runs either way.
+template <int ROWS> __device__ __forceinline__ int plane_pos(const int r, const int p) {
+    return (p >> 1) * (ROWS * 4) + r * 4 + (p & 1) * 2;
+}
+// ... and of 16-byte piece `idx` (row idx >> 1, channels 4 (idx & 1) ..) of a [ROWS][8] slice
+template <int ROWS> __device__ __forceinline__ int plane_pos4(const int idx) {
+    return (idx & 1) * (ROWS * 4) + (idx >> 1) * 4;
+}
 typedef unsigned int u32x4w __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // timing experiments (tools/wino_dbg.sh; results meaningless): 1 no global loads, 2 no transform +
@@ -237,7 +253,7 @@ __device__ __forceinline__ void wino_full_body(const WinoArgs& a, float* smem, c
         const f32x2 v1 = d[i * 4 + 1] + d[i * 4 + 2];
         const f32x2 v2 = d[i * 4 + 2] - d[i * 4 + 1];
         const f32x2 v3 = d[i * 4 + 1] - d[i * 4 + 3];
-        float* dst = Vs + stage * STAGE + (i * 4) * (WT * WP) + g_tile * WP + g_p * 2;
+        float* dst = Vs + stage * STAGE + (i * 4) * (WT * WP) + plane_pos<WT>(g_tile, g_p);
         *reinterpret_cast<f32x2*>(dst + 0 * WT * WP) = v0;
         *reinterpret_cast<f32x2*>(dst + 1 * WT * WP) = v1;
         *reinterpret_cast<f32x2*>(dst + 2 * WT * WP) = v2;
@@ -246,7 +262,7 @@ __device__ __forceinline__ void wino_full_body(const WinoArgs& a, float* smem, c
     auto store_u = [&](const int stage) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<f32x4*>(Us + stage * STAGE + (q * 4 + u_xi0) * (WK * WP) + u_idx * 4) = ur[q];
+            *reinterpret_cast<f32x4*>(Us + stage * STAGE + (q * 4 + u_xi0) * (WK * WP) + plane_pos4<WK>(u_idx)) = ur[q];
     };
     auto store_chunk = [&](const int stage) {
         if (CILRS_WINO_DBG & 2) {
@@ -278,8 +294,8 @@ __device__ __forceinline__ void wino_full_body(const WinoArgs& a, float* smem, c
     __syncthreads();
     // operand fragments: the k index of a lane is lq, it covers channels 2 lq, 2 lq + 1 of the
     // chunk (one 8-byte read feeds the two k-steps); 64 lanes read 512 contiguous bytes
-    const int frag_v = (tg * 16 + l15) * WP + lq * 2;
-    const int frag_u = (kg * 32 + l15) * WP + lq * 2;
+    const int frag_v = plane_pos<WT>(tg * 16 + l15, lq);
+    const int frag_u = plane_pos<WK>(kg * 32 + l15, lq);
     // fragments of xi + D are read while the MFMAs of xi run (an LDS read that an MFMA waits on
     // exposes its whole latency: with eight waves reading it is several hundred cycles)
     auto multiply = [&](const int ch) {
@@ -291,7 +307,7 @@ __device__ __forceinline__ void wino_full_body(const WinoArgs& a, float* smem, c
         for (int x = 0; x < D; ++x) {
             bv[x] = *reinterpret_cast<const f32x2*>(Vc + x * (WT * WP));
             a0[x] = *reinterpret_cast<const f32x2*>(Uc + x * (WK * WP));
-            a1[x] = *reinterpret_cast<const f32x2*>(Uc + x * (WK * WP) + 16 * WP);
+            a1[x] = *reinterpret_cast<const f32x2*>(Uc + x * (WK * WP) + 16 * 4);
         }
 #pragma unroll
         for (int xi = 0; xi < 16; ++xi) {
@@ -301,7 +317,7 @@ __device__ __forceinline__ void wino_full_body(const WinoArgs& a, float* smem, c
             } else if (xi + D < 16) {
                 bv[nxt] = *reinterpret_cast<const f32x2*>(Vc + (xi + D) * (WT * WP));
                 a0[nxt] = *reinterpret_cast<const f32x2*>(Uc + (xi + D) * (WK * WP));
-                a1[nxt] = *reinterpret_cast<const f32x2*>(Uc + (xi + D) * (WK * WP) + 16 * WP);
+                a1[nxt] = *reinterpret_cast<const f32x2*>(Uc + (xi + D) * (WK * WP) + 16 * 4);
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -553,7 +569,7 @@ __device__ __forceinline__ void wino_q_body(const WinoArgs& a, float* smem, cons
                 const f32x2 v1 = d[i * 4 + 1] + d[i * 4 + 2];
                 const f32x2 v2 = d[i * 4 + 2] - d[i * 4 + 1];
                 const f32x2 v3 = d[i * 4 + 1] - d[i * 4 + 3];
-                float* dst = Vs + stage * QSTAGE + (i * 4) * (QT * WP) + g_tile * WP + g_p * 2;
+                float* dst = Vs + stage * QSTAGE + (i * 4) * (QT * WP) + plane_pos<QT>(g_tile, g_p);
                 *reinterpret_cast<f32x2*>(dst + 0 * QT * WP) = v0;
                 *reinterpret_cast<f32x2*>(dst + 1 * QT * WP) = v1;
                 *reinterpret_cast<f32x2*>(dst + 2 * QT * WP) = v2;
@@ -562,15 +578,15 @@ __device__ __forceinline__ void wino_q_body(const WinoArgs& a, float* smem, cons
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            *reinterpret_cast<f32x4*>(Us + stage * QSTAGE + (2 * j + u_xi0) * (WK * WP) + u_idx * 4) = u[j];
+            *reinterpret_cast<f32x4*>(Us + stage * QSTAGE + (2 * j + u_xi0) * (WK * WP) + plane_pos4<WK>(u_idx)) = u[j];
     };
 
     // ---- consumers: rows = 16 channels (k0 + 16 wave ..), columns = the 16 tiles ----
     f32x4 acc[16];
 #pragma unroll
     for (int x = 0; x < 16; ++x) acc[x] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int frag_v = l15 * WP + lq * 2;
-    const int frag_u = ((wave & 3) * 16 + l15) * WP + lq * 2;
+    const int frag_v = plane_pos<QT>(l15, lq);
+    const int frag_u = plane_pos<WK>((wave & 3) * 16 + l15, lq);
     auto multiply = [&](const int ch) {
         const float* Vc = Vs + (ch & 1) * QSTAGE + frag_v;
         const float* Uc = Us + (ch & 1) * QSTAGE + frag_u;
