@@ -110,6 +110,7 @@ SIGNATURES = {
     "cilrs_bn16_train_fwd": (i32, [vp, i32, i32, vp, vp, vp, vp, vp, C.c_float, C.c_float, vp, i32,
                                    vp, vp, vp, i32, vp]),
     "cilrs_bn16_bwd": (i32, [vp, vp, vp, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, vp]),
+    "cilrs_conv2d_wino_split": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, sz, vp, vp, vp]),
     "cilrs_conv2d_wino_scratch_floats": (sz, [i32, i32]),
     "cilrs_conv2d_wino_fwd": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]),
     "cilrs_wino_filter_transform": (i32, [vp, vp, i32, i32, i32, vp]),

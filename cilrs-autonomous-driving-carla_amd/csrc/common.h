@@ -127,6 +127,11 @@ struct ConvArgs {
     ConvMulti multi;       // set by launch_conv_dgrad (stride 2)
 };
 int launch_conv_igemm(const ConvArgs& a, hipStream_t s);
+// fixed-order sum of dense [M][C] slabs (+ addend) with BatchNorm column partials [2][C][rows]
+int slab_reduce_rows(int M, int C, int* rows_per_block);
+int launch_slab_reduce_cols(int mode, const float* slabs, int splits, float* y, const float* addend,
+                            int M, int C, const float* bwd_z, const float* bwd_y,
+                            const float* bwd_stats, int bwd_relu, float* partial, hipStream_t s);
 // Data gradient of a forward conv (stride 1 or 2): dx[N,H,W,Cin] = dgrad(dy[N,Ho,Wo,Cout]) (+addend).
 // Stride 2 is decomposed into the four output-parity classes, each a dense stride-1 problem over
 // its own tap subset (no multiplications by the zeros of an up-sampled dy).
@@ -338,6 +343,13 @@ struct WinoArgs {
     const float* bwd_z; const float* bwd_y; const float* bwd_stats; int bwd_relu;
     float* bwd_partial;
     long long* stamps;       // diagnostics: block 0's waves 0 / 4 write 2 x 8 cycle counts (NULL: off)
+    // channel split (an under-filled launch: fewer blocks than CUs): the reduction over the C input
+    // channels is cut into `csplit` parts on csplit x as many blocks, each writes its partial
+    // result to a slab, the slabs are summed in fixed order by launch_slab_reduce_cols (which also
+    // applies the addend and emits the column partials).  slabs: caller's scratch of slab_floats
+    // floats (>= csplit * N*H*W*K to be considered); scratch_partial: where the reduce may park
+    // column partials nobody asked for.  csplit is filled in by the launcher.
+    float* slabs; size_t slab_floats; float* scratch_partial; int csplit;
     // filled in by launch_conv_wino (a launch = full 64-tile blocks + a tail of 16-tile blocks):
     int no_tail;             // caller: 1 = all tiles on the 64-tile kernel (one launch)
     int tile_begin;          // first output tile of this kernel's block 0
@@ -350,7 +362,8 @@ int launch_wino_weights(const float* w, float* U, int K, int C, int dgrad, hipSt
 bool wino_supported(int C, int K, int ksize, int stride, int pad);
 int wino_groups(int N, int H, int W);        // 64-tile groups of a launch
 // column-partial rows launch_conv_wino writes for these sizes (full groups + 16-tile tail groups)
-int wino_rows(int N, int H, int W, int K, int no_tail = 0);
+// (C > 0 and slab_floats: the channel split may change the answer)
+int wino_rows(int N, int H, int W, int K, int no_tail = 0, int C = 0, size_t slab_floats = 0);
 int launch_conv_wino(const WinoArgs& a, hipStream_t s);
 // Weight gradient of the same convolutions in the Winograd domain:
 //   dU_xi[k][c] = sum over tiles of (A dY A^T)_xi[tile][k] * (B^T d B)_xi[tile][c],  dw = G^T dU G

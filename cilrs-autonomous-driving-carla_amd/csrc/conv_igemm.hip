@@ -1082,6 +1082,33 @@ int launch_conv_igemm(const ConvArgs& a_in, hipStream_t s) {
     return 0;
 }
 
+// Sum `splits` dense [M][C] fp32 slabs in slab order into y (+ addend) and emit the BatchNorm column
+// partials of the result ([2][C][rows], rows = slab_reduce_rows): mode 0 forward statistics,
+// mode 1 BatchNorm-backward reductions.  Used by the channel-split Winograd launches
+// (conv_wino.hip); the same kernel as the implicit GEMM's split-K reduce.
+int slab_reduce_rows(int M, int C, int* rows_per_block) {
+    const int tpr = C >> 2, rpi = 256 / tpr;
+    const int rows = cdiv(cdiv(M, 1024), rpi) * rpi;
+    if (rows_per_block) *rows_per_block = rows;
+    return cdiv(M, rows);
+}
+int launch_slab_reduce_cols(int mode, const float* slabs, int splits, float* y, const float* addend,
+                            int M, int C, const float* bwd_z, const float* bwd_y,
+                            const float* bwd_stats, int bwd_relu, float* partial, hipStream_t s) {
+    CILRS_CHECK(slabs && y && partial && splits >= 1, "slab_reduce: NULL argument");
+    CILRS_CHECK(C % 4 == 0 && (C >> 2) <= 256 && 256 % (C >> 2) == 0, "slab_reduce: channel count %d", C);
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.y = y; a.addend = addend; a.Cout = C; a.y_ld = C;
+    a.bwd_z = bwd_z; a.bwd_y = bwd_y; a.bwd_stats = bwd_stats; a.bwd_relu = bwd_relu;
+    int rows = 0;
+    const int nblk = slab_reduce_rows(M, C, &rows);
+    if (mode == 0) splitk_reduce_cols_kernel<0><<<nblk, 256, 0, s>>>(a, slabs, M, splits, rows, partial);
+    else splitk_reduce_cols_kernel<1><<<nblk, 256, 0, s>>>(a, slabs, M, splits, rows, partial);
+    CILRS_LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_conv_dgrad(const DgradArgs& d, hipStream_t s) {
     CILRS_CHECK(d.stride == 1 || d.stride == 2, "dgrad: stride must be 1 or 2");
     CILRS_CHECK(d.K * d.K <= 16, "dgrad: filter too large");

@@ -186,9 +186,16 @@ __device__ __forceinline__ void wino_full_body(const WinoArgs& a, float* smem, c
     const int TH = (a.H + 1) >> 1, TW = (a.W + 1) >> 1;
     const int tiles_img = TH * TW, total_tiles = a.N * tiles_img;
     const int nkt = a.K / WK;
-    const int blk_n = bid % nkt, blk_m = bid / nkt;
+    // channel split: consecutive blocks = the parts of one tile's reduction
+    const int csplit = a.csplit > 1 ? a.csplit : 1;
+    const int part = bid % csplit;
+    const int tile_id = bid / csplit;
+    const int blk_n = tile_id % nkt, blk_m = tile_id / nkt;
     const int k0 = blk_n * WK;
-    const int nchunks = a.C / WC;
+    const int nchunks_all = a.C / WC;
+    const int per_part = (nchunks_all + csplit - 1) / csplit;
+    const int ch0 = part * per_part;                                   // first chunk of this block
+    const int nchunks = max(0, min(nchunks_all, ch0 + per_part) - ch0); // chunks of this block
 
     // ---- gather role (waves 0-3, one per SIMD): this thread's (tile, channel PAIR) and the 16
     //      patch pixels; 8-byte loads, packed additions, 8-byte LDS stores ----
@@ -218,7 +225,8 @@ __device__ __forceinline__ void wino_full_body(const WinoArgs& a, float* smem, c
 
     f32x2 d[16];
     f32x4 ur[4];
-    auto load_chunk = [&](const int ch) {
+    auto load_chunk = [&](const int ch_local) {
+        const int ch = ch0 + ch_local;                  // absolute chunk of the reduction
         if (CILRS_WINO_DBG & 1) {
 #pragma unroll
             for (int p = 0; p < 16; ++p) d[p] = f32x2{(float)(p + ch), 1.f};
@@ -236,7 +244,7 @@ __device__ __forceinline__ void wino_full_body(const WinoArgs& a, float* smem, c
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int xi = q * 4 + u_xi0;
-            const unsigned off = (unsigned)(xi * nchunks * a.K * 8 + u_idx * 4) * 4u;
+            const unsigned off = (unsigned)(xi * nchunks_all * a.K * 8 + u_idx * 4) * 4u;
             ur[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsU, (int)off, usoff, 0));
         }
     };
@@ -389,7 +397,11 @@ __device__ __forceinline__ void wino_full_body(const WinoArgs& a, float* smem, c
     const int co = k0 + kg * 32 + lq * 4;                   // + 16 mb
     const size_t ybytes = (size_t)a.N * a.H * a.W * a.K * 4;
     const int yrec = (int)(unsigned)ybytes;
-    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, yrec, 0x00020000);
+    // channel split: this block's partial result goes to slab `part`, raw (the reduce launch adds
+    // the addend and takes the column partials of the finished tensor)
+    const bool split = csplit > 1;
+    float* const ydst = split ? a.slabs + (size_t)part * (ybytes / 4) : a.y;
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)ydst, 0, yrec, 0x00020000);
     unsigned yoff[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -397,9 +409,10 @@ __device__ __forceinline__ void wino_full_body(const WinoArgs& a, float* smem, c
         const bool ok = tv && oy < a.H && ox < a.W;
         yoff[q] = ok ? (unsigned)((((n * a.H + oy) * a.W + ox) * a.K + co) * 4) : 0xFFFFFFFFu;
     }
-    const bool stats_fwd = a.bn_partial != nullptr, stats_bwd = a.bwd_partial != nullptr;
+    const bool stats_fwd = !split && a.bn_partial != nullptr, stats_bwd = !split && a.bwd_partial != nullptr;
+    const bool with_add = !split && a.addend != nullptr;
     f32x4 ad[2][4];
-    if (a.addend) {
+    if (with_add) {
         const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.addend, 0, yrec, 0x00020000);
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
@@ -422,7 +435,7 @@ __device__ __forceinline__ void wino_full_body(const WinoArgs& a, float* smem, c
         y[1] = s0[1] - s0[2] - s0[3];
         y[2] = s1[0] + s1[1] + s1[2];
         y[3] = s1[1] - s1[2] - s1[3];
-        if (a.addend) {
+        if (with_add) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) y[q] += ad[mb][q];
         }
@@ -1007,7 +1020,28 @@ static WinoSplit wino_split(int N, int H, int W, int K, int no_tail) {
     sp.tail = cdiv(tiles - sp.full * WT > 0 ? tiles - sp.full * WT : 0, QT);
     return sp;
 }
-int wino_rows(int N, int H, int W, int K, int no_tail) {
+// Channel split of an under-filled launch.  Cost model in shader cycles per block (in-kernel
+// stamps, profiles/r03_wino_dbg.log): ~6.0k per 8-channel chunk, ~10.5k prologue + epilogue; the
+// reduce launch + its boundary ~25k.  layer3 at B=128 (168 blocks, 32 chunks): 1 part 202k,
+// 2 parts (336 blocks = two rounds) 213k + 25k, 3 parts (504 blocks, two rounds) 149k + 25k.
+static int wino_csplit(int N, int H, int W, int C, int K, size_t slab_floats) {
+    const int cus = device_cus();
+    const int tiles = N * ((H + 1) / 2) * ((W + 1) / 2);
+    const int blocks = cdiv(tiles, WT) * (K / WK), nchunks = C / WC;
+    if (blocks >= cus || (K >> 2) > 256 || 256 % (K >> 2) != 0) return 1;
+    const size_t y_floats = (size_t)N * H * W * K;
+    int best = 1;
+    double best_t = 1e30;
+    for (int sp = 1; sp <= 4; ++sp) {
+        if (sp > 1 && ((size_t)sp * y_floats > slab_floats || nchunks / sp < 4)) break;
+        const double t = (double)cdiv(sp * blocks, cus) * (cdiv(nchunks, sp) * 6.0e3 + 10.5e3) +
+                         (sp > 1 ? 25.0e3 : 0.0);
+        if (t < 0.95 * best_t) { best_t = t; best = sp; }
+    }
+    return best;
+}
+int wino_rows(int N, int H, int W, int K, int no_tail, int C, size_t slab_floats) {
+    if (C > 0 && wino_csplit(N, H, W, C, K, slab_floats) > 1) return slab_reduce_rows(N * H * W, K, nullptr);
     const WinoSplit sp = wino_split(N, H, W, K, no_tail);
     return sp.full + sp.tail;
 }
@@ -1022,6 +1056,18 @@ int launch_conv_wino(const WinoArgs& a_in, hipStream_t s) {
                 "conv_wino: tensor too large for 32-bit offsets");
     CILRS_CHECK(!(a.bn_partial && a.bwd_partial), "conv_wino: one kind of column partials per launch");
     if (wino_prepare()) return 1;
+    a.csplit = (a.slabs && a.scratch_partial) ? wino_csplit(a.N, a.H, a.W, a.C, a.K, a.slab_floats) : 1;
+    if (a.csplit > 1) {
+        // every tile on the 64-tile kernel, csplit blocks per tile; then the fixed-order reduce
+        a.tile_begin = 0; a.row0 = 0; a.rows = 0;
+        const int nfull = wino_groups(a.N, a.H, a.W) * (a.K / WK) * a.csplit;
+        conv_wino_kernel<<<nfull, WTHREADS, kWinoLds, s>>>(a, a, nfull);
+        CILRS_LAUNCH_CHECK();
+        const int mode = a.bwd_partial ? 1 : 0;
+        float* partial = a.bwd_partial ? a.bwd_partial : a.bn_partial ? a.bn_partial : a.scratch_partial;
+        return launch_slab_reduce_cols(mode, a.slabs, a.csplit, a.y, a.addend, a.N * a.H * a.W, a.K,
+                                       a.bwd_z, a.bwd_y, a.bwd_stats, a.bwd_relu, partial, s);
+    }
     const WinoSplit sp = wino_split(a.N, a.H, a.W, a.K, a.no_tail);
     a.rows = sp.full + sp.tail;
     WinoArgs t = a;

@@ -487,7 +487,9 @@ int conv_fwd(cilrs_net* net, const ConvT& c, const ConvG& g, const float* x, int
         wa.x = x; wa.U = ws + net->wino_base + net->wino_table.u[e]; wa.y = y;
         wa.N = net->B; wa.H = g.H; wa.W = g.W; wa.C = c.cin; wa.K = c.cout;
         wa.bn_partial = ws + net->bn_partial;
-        *bn_nblk = wino_rows(net->B, g.H, g.W, c.cout);
+        wa.slabs = ws + net->ksplit; wa.slab_floats = net->ksplit_floats;
+        wa.scratch_partial = ws + net->bn_partial;
+        *bn_nblk = wino_rows(net->B, g.H, g.W, c.cout, 0, c.cin, net->ksplit_floats);
         const double flops = 2.0 * g.M * c.cout * c.k * c.k * c.cin;      // DIRECT-convolution flops
         const double bytes = 4.0 * ((double)net->B * g.H * g.W * c.cin + (double)g.M * c.cout +
                                     16.0 * c.cout * c.cin);
@@ -539,11 +541,13 @@ int conv_dgrad(cilrs_net* net, const ConvT& c, const ConvG& g, const float* dy, 
         // (decided by the plan's configuration, not by whether this step is being profiled: the
         //  profiled steps of bench.py must run the kernels the timed steps ran)
         wa.no_tail = overlap_configured(net) ? 1 : 0;
+        wa.slabs = ws + net->ksplit; wa.slab_floats = net->ksplit_floats;
+        wa.scratch_partial = ws + net->bn_partial;
         if (bwd_nblk) *bwd_nblk = 0;
         if (bn_of && bwd_nblk) {
             wa.bwd_z = ws + bn_of->z; wa.bwd_y = ws + bn_of->y; wa.bwd_stats = ws + bn_of->stats;
             wa.bwd_relu = bn_relu; wa.bwd_partial = ws + net->bn_partial;
-            *bwd_nblk = wino_rows(net->B, g.H, g.W, c.cin, wa.no_tail);
+            *bwd_nblk = wino_rows(net->B, g.H, g.W, c.cin, wa.no_tail, c.cout, net->ksplit_floats);
         }
         const double flops = 2.0 * g.M * c.cout * c.k * c.k * c.cin;
         const double bytes = 4.0 * ((double)net->B * g.H * g.W * c.cin + (double)g.M * c.cout +
@@ -2654,6 +2658,20 @@ int cilrs_conv2d_wino_pre(const float* x, const float* U, float* y, const float*
     memset(&a, 0, sizeof(a));
     a.x = x; a.U = U; a.y = y; a.addend = addend; a.N = N; a.H = H; a.W = W; a.C = Cred; a.K = Cout;
     a.stamps = g_wino_stamps;        // diagnostics: cilrs_conv2d_wino_stamps (tools/wino_bench.py)
+    return launch_conv_wino(a, reinterpret_cast<hipStream_t>(stream));
+}
+
+int cilrs_conv2d_wino_split(const float* x, const float* U, float* y, const float* addend,
+                            float* bn_partial, int N, int H, int W, int Cred, int Cout, float* slabs,
+                            size_t slab_floats, int* csplit, int* partial_rows, void* stream) {
+    CILRS_CHECK(x && U && y && bn_partial && slabs, "conv2d_wino_split: NULL argument");
+    WinoArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.U = U; a.y = y; a.addend = addend; a.N = N; a.H = H; a.W = W; a.C = Cred; a.K = Cout;
+    a.bn_partial = bn_partial; a.slabs = slabs; a.slab_floats = slab_floats;
+    a.scratch_partial = bn_partial;
+    if (partial_rows) *partial_rows = wino_rows(N, H, W, Cout, 0, Cred, slab_floats);
+    if (csplit) *csplit = wino_rows(N, H, W, Cout, 0, Cred, slab_floats) != wino_rows(N, H, W, Cout, 0);
     return launch_conv_wino(a, reinterpret_cast<hipStream_t>(stream));
 }
 

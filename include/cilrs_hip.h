@@ -437,6 +437,14 @@ int cilrs_wino_filter_transform(const float* w, float* U, int Cin, int Cout, int
 int cilrs_conv2d_wino_stamps(long long* stamps16);
 int cilrs_conv2d_wino_pre(const float* x, const float* U, float* y, const float* addend, int N, int H,
                           int W, int Cred, int Cout, void* stream);
+/* cilrs_conv2d_wino_pre with the launch plan of the train step: an under-filled launch (fewer 64-tile
+ * x 64-channel blocks than CUs: layer3 at B=128) is cut along the reduction over the Cred input
+ * channels into up to four parts per tile, each part writes a slab, and a fixed-order reduce sums
+ * them, adds the addend and emits the BatchNorm column partials [2][Cout][*partial_rows].
+ * slabs: scratch of slab_floats floats; *csplit = 1 if the split path ran. */
+int cilrs_conv2d_wino_split(const float* x, const float* U, float* y, const float* addend,
+                            float* bn_partial, int N, int H, int W, int Cred, int Cout, float* slabs,
+                            size_t slab_floats, int* csplit, int* partial_rows, void* stream);
 int cilrs_conv2d_wino_dgrad(const float* dy, const float* w, float* dx, const float* addend, int N,
                             int H, int W, int Cin, int Cout, float* scratch, void* stream);
 /* Weight gradient of the same convolution in the Winograd domain (cuDNN conv bwd-filter, i.e. the

@@ -593,6 +593,51 @@ def test_conv16_fwd_dgrad_wgrad(case, bf16):
     assert (dw.cpu().double() - want).abs().max() <= 5e-5 * float(want.abs().max())
 
 
+def test_conv_wino_channel_split_of_an_underfilled_launch():
+    """layer3 at the benchmark batch: 168 64-tile x 64-channel blocks on 256 CUs.  The train step's
+    launch plan cuts the reduction over the 256 input channels into three parts (504 blocks, two
+    rounds of a third of the work), every part writes a slab, and a fixed-order reduce sums the
+    slabs, adds the addend and emits the BatchNorm column partials.  Same contract as the one-part
+    launch: 5e-5 of max|ref| against torch's direct convolution; partials = column sums of the
+    result."""
+    L = _lib()
+    lib = L.lib()
+    N, H, W, Cc = 128, 6, 13, 256
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(N, Cc, H, W, generator=g)
+    w = torch.randn(Cc, Cc, 3, 3, generator=g) / (9 * Cc) ** 0.5
+    add = torch.randn(N, H, W, Cc, generator=g)
+    torch.set_num_threads(16)
+    ref = F.conv2d(x, w, None, 1, 1).permute(0, 2, 3, 1) + add
+    xd, wd, addd = nhwc(x), ohwi(w), dev(add)
+    U = torch.empty(lib.cilrs_conv2d_wino_scratch_floats(Cc, Cc), device="cuda")
+    L.check(lib.cilrs_wino_filter_transform(L.ptr(wd), L.ptr(U), Cc, Cc, 0, stream()))
+    M = N * H * W
+    slabs = torch.full((4 * M * Cc,), float("nan"), device="cuda")
+    part = torch.full((2 * Cc * 1024,), float("nan"), device="cuda")
+    y = torch.full((N, H, W, Cc), float("nan"), device="cuda")
+    cs, rows = C.c_int(0), C.c_int(0)
+    L.check(lib.cilrs_conv2d_wino_split(L.ptr(xd), L.ptr(U), L.ptr(y), L.ptr(addd), L.ptr(part), N, H,
+                                        W, Cc, Cc, L.ptr(slabs), slabs.numel(), C.byref(cs),
+                                        C.byref(rows), stream()))
+    torch.cuda.synchronize()
+    assert cs.value == 1, "the launch plan did not split this launch"
+    got = y.cpu()
+    assert torch.isfinite(got).all()
+    assert float((got - ref).abs().max()) <= _tol(ref, 5e-5)
+    pp = part[:2 * Cc * rows.value].cpu().double().view(2, Cc, rows.value).sum(-1)
+    flat = got.double().reshape(M, Cc)
+    assert (pp[0] - flat.sum(0)).abs().max() <= 1e-4 * max(1.0, float(flat.sum(0).abs().max()))
+    assert (pp[1] - (flat ** 2).sum(0)).abs().max() <= 1e-4 * float((flat ** 2).sum(0).max())
+    # without scratch the same call runs the one-part launch: identical contract, bitwise its own
+    y2 = torch.full((N, H, W, Cc), float("nan"), device="cuda")
+    L.check(lib.cilrs_conv2d_wino_pre(L.ptr(xd), L.ptr(U), L.ptr(y2), L.ptr(addd), N, H, W, Cc, Cc,
+                                      stream()))
+    torch.cuda.synchronize()
+    assert float((y2.cpu() - ref).abs().max()) <= _tol(ref, 5e-5)
+    assert float((y2.cpu() - got).abs().max()) <= _tol(ref, 2e-5)     # (another summation order)
+
+
 # ---- the bf16 training mode's operators on 16-bit tensors (round 4) ------------------------------
 CONV16T_CASES = [
     # N, H, W, Cin, Cout, k, s, p                 tile the launch plan picks on a 256-CU device
