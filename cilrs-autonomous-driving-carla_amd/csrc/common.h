@@ -507,6 +507,7 @@ struct ConvF16Args {
 int launch_conv_f16_train(const ConvF16Args& a, hipStream_t s);
 int conv_f16_train_mtiles(const ConvF16Args& a);         // rows of the column partials it writes
 int launch_conv16_large(const ConvF16Args& a, hipStream_t s);   // conv16.hip; -1: not taken
+void conv_f16_up2_classes(ConvF16Args& c);               // fills the parity-class tables (up2 = 2)
 bool conv_f16_train_can_fuse_bwd(const ConvF16Args& a);  // BatchNorm-backward partials possible?
 // wT[ci][K-1-kh][K-1-kw][co] = (16-bit) w[co][kh][kw][ci]
 int launch_transpose_flip_f16(const float* w, void* wT, int Cout, int K, int Cin, int bf16,

@@ -473,6 +473,11 @@ int launch_conv16p(const ConvF16Args& a, const Conv16Plan& p, hipStream_t s) {
 
 // rows of the [2][Cout][M-tiles] column partials (bn_partial / bwd_partial) a launch writes
 int conv_f16_train_mtiles(const ConvF16Args& a) {
+    if (a.up2) {                 // four parity classes, 64-row tiles each (infer_f16.hip)
+        ConvF16Args c = a;
+        conv_f16_up2_classes(c);
+        return c.cls_tile_begin[4] / (c.Cout / 64);
+    }
     return cdiv(a.N * a.Ho * a.Wo, conv16_plan(a).bm);
 }
 

@@ -66,11 +66,21 @@ __global__ __launch_bounds__(256, (BM == 64 ? 2 : 2)) void conv_f16_kernel(const
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
         logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
+    // stride-2 data gradient by output-parity class (up2 == 2): this block's class, its own
+    // enumerated grid [N][cHo][cWo] (pixel (2 i + ph, 2 j + pw) of the gradient) and tap subset
+    int cls = 0, cHo = a.Ho, cWo = a.Wo, mt_base = 0;
+    if (TRAIN && a.up2 == 2) {
+        while (cls < 3 && logical >= a.cls_tile_begin[cls + 1]) ++cls;
+        logical -= a.cls_tile_begin[cls];
+        cHo = a.cls_Ho[cls]; cWo = a.cls_Wo[cls];
+        mt_base = a.cls_tile_begin[cls] / tilesN;
+    }
     const int m0 = (logical / tilesN) * BM, n0 = (logical % tilesN) * BN;
-    const int M = a.N * a.Ho * a.Wo, HoWo = a.Ho * a.Wo;
-    const int ntaps = a.K * a.K, cin_tiles = a.Cin / HBK;
+    const int M = a.N * cHo * cWo, HoWo = cHo * cWo;
+    const int ntaps_all = a.K * a.K, cin_tiles = a.Cin / HBK;
+    const int ntaps = (TRAIN && a.up2 == 2) ? a.cls_ntaps[cls] : ntaps_all;
     const int nt = ntaps * cin_tiles;
-    const long Krow = (long)ntaps * a.Cin;
+    const long Krow = (long)ntaps_all * a.Cin;
 
     // per-thread gather rows: rows r0 + 32 i, 16-byte chunk kq of the 128-byte K-tile row
     const int kq = tid & 7, r0 = tid >> 3;
@@ -82,8 +92,15 @@ __global__ __launch_bounds__(256, (BM == 64 ? 2 : 2)) void conv_f16_kernel(const
         rowOff[i] = 0u;
         if (m < M) {
             const int n = m / HoWo, rem = m - n * HoWo;
-            const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
-            if (TRAIN && a.up2) {
+            const int oh = rem / cWo, ow = rem - oh * cWo;
+            if (TRAIN && a.up2 == 2) {
+                // base = gathered pixel (oh, ow) of dy; tap t sits (cls_dh, cls_dw) away from it
+                rowOff[i] = (unsigned)((((long)(n * a.H + oh) * a.W + ow) * a.Cin + kq * 8) * 2);
+                for (int t = 0; t < ntaps; ++t) {
+                    const int h2 = oh + a.cls_dh[cls][t], w2 = ow + a.cls_dw[cls][t];
+                    if (h2 >= 0 && w2 >= 0 && h2 < a.H && w2 < a.W) rowMask[i] |= 1u << t;
+                }
+            } else if (TRAIN && a.up2) {
                 // parity-matching taps of row (oh + pad) sit at (oh + pad)/2 - kh/2 (see up2)
                 const int bh = oh + a.pad, bw = ow + a.pad;
                 rowOff[i] = (unsigned)((((long)(n * a.H + (bh >> 1)) * a.W + (bw >> 1)) * a.Cin +
@@ -110,13 +127,15 @@ __global__ __launch_bounds__(256, (BM == 64 ? 2 : 2)) void conv_f16_kernel(const
         wOff[i] = (unsigned)(((long)(n0 + r0 + 32 * i) * Krow + kq * 8) * 2);
     int tapA_v = 0, tapB_v = 0;              // per-tap byte offsets, one tap per lane
     if (lane < ntaps) {
-        if (TRAIN && a.up2) {
+        if (TRAIN && a.up2 == 2) {
+            tapA_v = (a.cls_dh[cls][lane] * a.W + a.cls_dw[cls][lane]) * a.Cin * 2;
+        } else if (TRAIN && a.up2) {
             const int kh = a.K - 1 - lane / a.K, kw = a.K - 1 - lane % a.K;
             tapA_v = -(((kh >> 1) * a.W + (kw >> 1)) * a.Cin * 2);
         } else {
             tapA_v = ((lane / a.K) * a.W + lane % a.K) * a.Cin * 2;
         }
-        tapB_v = lane * a.Cin * 2;
+        tapB_v = ((TRAIN && a.up2 == 2) ? a.cls_tap[cls][lane] : lane) * a.Cin * 2;
     }
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
         (void*)a.x, 0, (int)(unsigned)((size_t)a.N * a.H * a.W * a.Cin * 2), 0x00020000);
@@ -220,6 +239,9 @@ __global__ __launch_bounds__(256, (BM == 64 ? 2 : 2)) void conv_f16_kernel(const
         float* stage = reinterpret_cast<float*>(smem_raw);
         constexpr int SP = BN + 4;
         const bool out16 = a.y16 != nullptr;
+        // rows of the column partials: the launch's M-tiles (all parity classes of a stride-2 gradient)
+        const size_t nmt_all = a.up2 == 2 ? (size_t)(a.cls_tile_begin[4] / tilesN)
+                                          : (size_t)((M + BM - 1) / BM);
         if (a.bn_partial != nullptr) {
             float* red = stage;                           // [2][BN][2]
 #pragma unroll
@@ -244,7 +266,7 @@ __global__ __launch_bounds__(256, (BM == 64 ? 2 : 2)) void conv_f16_kernel(const
             if (tid < BN) {
                 const float t1 = red[tid * 2] + red[(BN + tid) * 2];
                 const float t2 = red[tid * 2 + 1] + red[(BN + tid) * 2 + 1];
-                const size_t mt = (size_t)(logical / tilesN), nmt = (size_t)((M + BM - 1) / BM);
+                const size_t mt = (size_t)(mt_base + logical / tilesN), nmt = nmt_all;
                 a.bn_partial[(size_t)(n0 + tid) * nmt + mt] = t1;
                 a.bn_partial[(size_t)(a.Cout + n0 + tid) * nmt + mt] = t2;
             }
@@ -284,7 +306,13 @@ __global__ __launch_bounds__(256, (BM == 64 ? 2 : 2)) void conv_f16_kernel(const
             if (m >= M) continue;
             f32x4 lo = *reinterpret_cast<const f32x4*>(&stage[row * SP + c8]);
             f32x4 hi = *reinterpret_cast<const f32x4*>(&stage[row * SP + c8 + 4]);
-            const size_t o = (size_t)m * a.Cout + n0 + c8;
+            size_t pix = (size_t)m;
+            if (a.up2 == 2) {           // row m of the class grid -> pixel (2 i + ph, 2 j + pw) of dx
+                const int n = m / HoWo, rem = m - n * HoWo;
+                const int ci = rem / cWo, cj = rem - ci * cWo;
+                pix = ((size_t)n * a.Ho + 2 * ci + a.cls_ph[cls]) * a.Wo + 2 * cj + a.cls_pw[cls];
+            }
+            const size_t o = pix * a.Cout + n0 + c8;
             if (a.addend32) {
                 lo += *reinterpret_cast<const f32x4*>(a.addend32 + o);
                 hi += *reinterpret_cast<const f32x4*>(a.addend32 + o + 4);
@@ -368,7 +396,7 @@ __global__ __launch_bounds__(256, (BM == 64 ? 2 : 2)) void conv_f16_kernel(const
                     t1 += red1[r * BN + tid];
                     t2 += red2[r * BN + tid];
                 }
-                const size_t mt = (size_t)(logical / tilesN), nmt = (size_t)((M + BM - 1) / BM);
+                const size_t mt = (size_t)(mt_base + logical / tilesN), nmt = nmt_all;
                 a.bwd_partial[(size_t)(n0 + tid) * nmt + mt] = t1;
                 a.bwd_partial[(size_t)(a.Cout + n0 + tid) * nmt + mt] = t2;
             }
@@ -507,6 +535,50 @@ int launch_conv_f16(const ConvF16Args& a, hipStream_t s) {
                   : launch_conv_f16_cfg<_Float16, 64, 64>(a, M, s);
 }
 
+// Parity classes of a stride-2 data gradient.  Forward: y[oh][ow] = sum x[2 oh - p + kh][..] w[kh][..],
+// so dx[h][w] only receives taps with kh = (h + p) mod 2 (mod 2), kw likewise: 1 + 2 + 2 + 4 of the 9
+// taps of a 3x3 filter over the four classes (h + p, w + p) mod 2 -- 2.25 taps per pixel instead of
+// the 9 (seven of them masked to zero) the up-sampled form multiplies; a 1x1 / stride-2 filter has
+// one class with one tap and three classes that only copy the addend.  Class (ph, pw) enumerates
+// dx pixels (2 i + h0, 2 j + w0), h0 = (ph - p) mod 2; tap kh reads dy row i + (h0 + p - kh) / 2.
+// Weights: the transposed, tap-FLIPPED copy wT[ci][K-1-kh][K-1-kw][co] (flipped index into cls_tap).
+void conv_f16_up2_classes(ConvF16Args& c) {
+    const int K = c.K, p = c.pad, tilesN = c.Cout / 64;
+    c.up2 = 2;
+    c.cls_tile_begin[0] = 0;
+    for (int cls = 0; cls < 4; ++cls) {
+        const int ph = cls >> 1, pw = cls & 1;                 // (h + p) mod 2, (w + p) mod 2
+        const int h0 = ((ph - p) % 2 + 2) % 2, w0 = ((pw - p) % 2 + 2) % 2;
+        c.cls_ph[cls] = h0; c.cls_pw[cls] = w0;
+        c.cls_Ho[cls] = c.Ho > h0 ? (c.Ho - h0 + 1) / 2 : 0;
+        c.cls_Wo[cls] = c.Wo > w0 ? (c.Wo - w0 + 1) / 2 : 0;
+        int nt = 0;
+        for (int kh = ph; kh < K; kh += 2)
+            for (int kw = pw; kw < K; kw += 2) {
+                c.cls_tap[cls][nt] = (K - 1 - kh) * K + (K - 1 - kw);
+                c.cls_dh[cls][nt] = (h0 + p - kh) / 2;          // exact: h0 + p - kh is even
+                c.cls_dw[cls][nt] = (w0 + p - kw) / 2;
+                ++nt;
+            }
+        c.cls_ntaps[cls] = nt;
+        const int Mc = c.N * c.cls_Ho[cls] * c.cls_Wo[cls];
+        c.cls_tile_begin[cls + 1] = c.cls_tile_begin[cls] + cdiv(Mc, 64) * tilesN;
+    }
+}
+
+template <typename T>
+static int launch_conv_f16_train_blocks(const ConvF16Args& a, int blocks, hipStream_t s) {
+    constexpr size_t lds = (size_t)2 * (64 + 64) * HPITCH * 2;
+    if (once_per_device(reinterpret_cast<const void*>(&conv_f16_kernel<T, 64, 64, true>)))
+        CILRS_HIP(hipFuncSetAttribute(
+            reinterpret_cast<const void*>(&conv_f16_kernel<T, 64, 64, true>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (blocks <= 0) return 0;
+    conv_f16_kernel<T, 64, 64, true><<<blocks, 256, lds, s>>>(a);
+    CILRS_LAUNCH_CHECK();
+    return 0;
+}
+
 template <typename T>
 static int launch_conv_f16_train_t(const ConvF16Args& a, int M, hipStream_t s) {
     constexpr size_t lds = (size_t)2 * (64 + 64) * HPITCH * 2;
@@ -525,7 +597,7 @@ static int launch_conv_f16_train_t(const ConvF16Args& a, int M, hipStream_t s) {
 // (conv_f16_train_mtiles -- rows of the column partials a launch writes -- lives with the tile plan
 //  in conv16.hip)
 // may the BatchNorm-backward reductions ride on this launch's epilogue?
-bool conv_f16_train_can_fuse_bwd(const ConvF16Args& a) { return a.up2 == 0; }
+bool conv_f16_train_can_fuse_bwd(const ConvF16Args& a) { (void)a; return true; }   // (parity classes included)
 
 int launch_conv_f16_train(const ConvF16Args& a, hipStream_t s) {
     CILRS_CHECK(a.Cin % HBK == 0 && a.Cout % 64 == 0 && a.K * a.K <= 16,
@@ -537,10 +609,17 @@ int launch_conv_f16_train(const ConvF16Args& a, hipStream_t s) {
     CILRS_CHECK((size_t)a.N * a.H * a.W * a.Cin * 2 < (1ull << 32), "conv_f16_train: input too large");
     CILRS_CHECK(!a.up2 || a.stride == 2, "conv_f16_train: up2 is the stride-2 data gradient");
     CILRS_CHECK(!a.bwd_partial ||
-                    (a.bwd_stats && !a.up2 &&
+                    (a.bwd_stats &&
                      ((a.bwd_y && (a.bwd_z || !a.bwd_relu)) || (a.bwd_y16 && (a.bwd_z16 || !a.bwd_relu)))),
-                "conv_f16_train: BatchNorm-backward partials need y / stats (/ z), stride 1");
+                "conv_f16_train: BatchNorm-backward partials need y / stats (/ z)");
     const int M = a.N * a.Ho * a.Wo;
+    if (a.up2 == 1) {           // stride-2 data gradient: ONE launch over the four parity classes
+        ConvF16Args c = a;
+        conv_f16_up2_classes(c);
+        const int blocks = c.cls_tile_begin[4];
+        return a.bf16 ? launch_conv_f16_train_blocks<__bf16>(c, blocks, s)
+                      : launch_conv_f16_train_blocks<_Float16>(c, blocks, s);
+    }
     // large layers: persistent 128-row tiles (conv16.hip); -1 = this launch stays on 64x64
     const int rc = launch_conv16_large(a, s);
     if (rc >= 0) return rc;

@@ -424,7 +424,18 @@ int ensure_streams(cilrs_net* net) {
     // side stream 0 carries the weight-gradient GEMMs (CILRS_SIDE_PRIO=1: lowest priority -- an
     // experiment that starves them, see kDyRing)
     static const int side_prio = experiment_env("CILRS_SIDE_PRIO", 0);
-    if (side_prio)
+    // experiment (CILRS_SIDE_CUS=n, CILRS_SIDE_CU_MODE=0|1): confine the weight-gradient stream to n
+    // CUs (mode 0: CU ids 0..n-1; mode 1: ids with (id % 32) < n / 8, i.e. n / 8 per group of 32)
+    static const int side_cus = experiment_env("CILRS_SIDE_CUS", 0);
+    static const int side_cu_mode = experiment_env("CILRS_SIDE_CU_MODE", 0);
+    if (side_cus > 0) {
+        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int id = 0; id < 256; ++id) {
+            const bool on = side_cu_mode == 0 ? id < side_cus : (id % 32) < side_cus / 8;
+            if (on) mask[id >> 5] |= 1u << (id & 31);
+        }
+        CILRS_HIP(hipExtStreamCreateWithCUMask(&net->side[0], 8, mask));
+    } else if (side_prio)
         CILRS_HIP(hipStreamCreateWithPriority(&net->side[0], hipStreamNonBlocking, prio_least));
     else
         CILRS_HIP(hipStreamCreateWithFlags(&net->side[0], hipStreamNonBlocking));
