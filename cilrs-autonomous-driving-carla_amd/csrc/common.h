@@ -365,6 +365,7 @@ int wino_groups(int N, int H, int W);        // 64-tile groups of a launch
 // (C > 0 and slab_floats: the channel split may change the answer)
 int wino_rows(int N, int H, int W, int K, int no_tail = 0, int C = 0, size_t slab_floats = 0);
 int launch_conv_wino(const WinoArgs& a, hipStream_t s);
+int wino_last_csplit();                      // parts per tile of the most recent launch
 // Weight gradient of the same convolutions in the Winograd domain:
 //   dU_xi[k][c] = sum over tiles of (A dY A^T)_xi[tile][k] * (B^T d B)_xi[tile][c],  dw = G^T dU G
 // (16 products per tile, channel pair and tap set instead of 36).  The tile range is split over

@@ -1169,6 +1169,12 @@ int launch_conv_dgrad(const DgradArgs& d, hipStream_t s) {
                         ++k.nt;
                     }
                 }
+                // a class no tap reaches (three of the four of a 1x1 / stride-2 filter) has nothing
+                // to add: when the result accumulates IN PLACE (addend == dx, no mask) its pixels
+                // already hold their final value -- no blocks for it (the down-sample branch's
+                // data gradient then touches a quarter of dx instead of reading and rewriting all
+                // of it: 70 -> ~25 us at B=128)
+                if (k.nt == 0 && d.addend == d.dx && d.addend != nullptr && d.mask == nullptr) continue;
                 cl[ncl++] = k;
             }
         for (int i = 1; i < ncl; ++i)                        // longest K first (stable)

@@ -1046,6 +1046,9 @@ int wino_rows(int N, int H, int W, int K, int no_tail, int C, size_t slab_floats
     return sp.full + sp.tail;
 }
 
+static int g_last_csplit = 0;
+int wino_last_csplit() { return g_last_csplit; }     // parts per tile of the most recent launch (tests)
+
 int launch_conv_wino(const WinoArgs& a_in, hipStream_t s) {
     WinoArgs a = a_in;
     CILRS_CHECK(a.x && a.U && a.y, "conv_wino: NULL tensor");
@@ -1057,6 +1060,7 @@ int launch_conv_wino(const WinoArgs& a_in, hipStream_t s) {
     CILRS_CHECK(!(a.bn_partial && a.bwd_partial), "conv_wino: one kind of column partials per launch");
     if (wino_prepare()) return 1;
     a.csplit = (a.slabs && a.scratch_partial) ? wino_csplit(a.N, a.H, a.W, a.C, a.K, a.slab_floats) : 1;
+    g_last_csplit = a.csplit;
     if (a.csplit > 1) {
         // every tile on the 64-tile kernel, csplit blocks per tile; then the fixed-order reduce
         a.tile_begin = 0; a.row0 = 0; a.rows = 0;

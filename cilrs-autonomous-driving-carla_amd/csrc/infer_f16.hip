@@ -561,7 +561,9 @@ void conv_f16_up2_classes(ConvF16Args& c) {
                 ++nt;
             }
         c.cls_ntaps[cls] = nt;
-        const int Mc = c.N * c.cls_Ho[cls] * c.cls_Wo[cls];
+        // (a class no tap reaches only copies the addend: nothing to do when that is in place)
+        const bool in_place = c.y16 != nullptr && c.addend16 == c.y16 && !c.bwd_partial;
+        const int Mc = (nt == 0 && in_place) ? 0 : c.N * c.cls_Ho[cls] * c.cls_Wo[cls];
         c.cls_tile_begin[cls + 1] = c.cls_tile_begin[cls] + cdiv(Mc, 64) * tilesN;
     }
 }

@@ -2682,8 +2682,9 @@ int cilrs_conv2d_wino_split(const float* x, const float* U, float* y, const floa
     a.bn_partial = bn_partial; a.slabs = slabs; a.slab_floats = slab_floats;
     a.scratch_partial = bn_partial;
     if (partial_rows) *partial_rows = wino_rows(N, H, W, Cout, 0, Cred, slab_floats);
-    if (csplit) *csplit = wino_rows(N, H, W, Cout, 0, Cred, slab_floats) != wino_rows(N, H, W, Cout, 0);
-    return launch_conv_wino(a, reinterpret_cast<hipStream_t>(stream));
+    const int rc = launch_conv_wino(a, reinterpret_cast<hipStream_t>(stream));
+    if (csplit) *csplit = wino_last_csplit();
+    return rc;
 }
 
 int cilrs_conv2d_wino_dgrad(const float* dy, const float* w, float* dx, const float* addend, int N,

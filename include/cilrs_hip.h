@@ -441,7 +441,7 @@ int cilrs_conv2d_wino_pre(const float* x, const float* U, float* y, const float*
  * x 64-channel blocks than CUs: layer3 at B=128) is cut along the reduction over the Cred input
  * channels into up to four parts per tile, each part writes a slab, and a fixed-order reduce sums
  * them, adds the addend and emits the BatchNorm column partials [2][Cout][*partial_rows].
- * slabs: scratch of slab_floats floats; *csplit = 1 if the split path ran. */
+ * slabs: scratch of slab_floats floats; *csplit = parts per tile the launch used (1: not split). */
 int cilrs_conv2d_wino_split(const float* x, const float* U, float* y, const float* addend,
                             float* bn_partial, int N, int H, int W, int Cred, int Cout, float* slabs,
                             size_t slab_floats, int* csplit, int* partial_rows, void* stream);
