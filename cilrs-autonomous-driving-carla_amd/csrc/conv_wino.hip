@@ -68,6 +68,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef CILRS_WINO_DBG
 #define CILRS_WINO_DBG 0
 #endif
+// K loop structure (compile-time: a run-time choice between the two bodies spills ~400 VGPRs):
+// 0 = two phases per chunk (half the waves multiply while the other half refills, then swap; two
+// barriers), 1 = one barrier per chunk (every wave multiplies chunk ch, then stores its part of
+// chunk ch + 1 into the other stage).  tools/wino_dbg.sh builds the other variant for A/B.
+#ifndef CILRS_WINO_ONE_PHASE
+#define CILRS_WINO_ONE_PHASE 0
+#endif
 
 // u = G g G^T;  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
 __device__ __forceinline__ void wino_filter(const float (&g)[3][3], float (&u)[16]) {
@@ -366,6 +373,17 @@ __device__ __forceinline__ void wino_full_body(const WinoArgs& a, float* smem, c
     for (int ch = 0; ch < nchunks; ++ch) {
         long long ta = 0, tb = 0, tc = 0;
         if (stamp) ta = __builtin_amdgcn_s_memtime();
+        if constexpr (CILRS_WINO_ONE_PHASE != 0) {
+            // ONE barrier per chunk: every wave multiplies chunk ch (stage ch & 1), then stores its
+            // part of chunk ch + 1 into the OTHER stage -- nobody reads that stage before the
+            // barrier, and nobody overwrites stage ch & 1 before every wave has passed it
+            multiply(ch);
+            refill(ch);
+            if (stamp) tb = tc = __builtin_amdgcn_s_memtime();
+            __syncthreads();
+            if (stamp) { tm_a += tb - ta; tm_bar += __builtin_amdgcn_s_memtime() - tc; }
+            continue;
+        } else {
         if (late) {
             refill(ch);
             __builtin_amdgcn_sched_barrier(0);
@@ -385,6 +403,7 @@ __device__ __forceinline__ void wino_full_body(const WinoArgs& a, float* smem, c
             tm_a += tb - ta;
             tm_b += tc - tb;
             tm_bar += __builtin_amdgcn_s_memtime() - tc;
+        }
         }
     }
     const long long tm_loop1 = stamp ? __builtin_amdgcn_s_memtime() : 0;
@@ -918,6 +937,11 @@ __global__ __launch_bounds__(WTHREADS) void wino_wgrad_kernel(const WinoWgradArg
     __syncthreads();
     const bool late = wave >= 4;
     for (int ch = 0; ch < nchunks; ++ch) {
+        if constexpr (CILRS_WINO_ONE_PHASE != 0) {                   // (see conv_wino_kernel)
+            multiply(ch);
+            if (ch + 1 < nchunks) { store_chunk((ch + 1) & 1); if (ch + 2 < nchunks) load_chunk(); }
+            __syncthreads();
+        } else {
         if (late) {
             if (ch + 1 < nchunks) { store_chunk((ch + 1) & 1); if (ch + 2 < nchunks) load_chunk(); }
             __builtin_amdgcn_sched_barrier(0);
@@ -930,6 +954,7 @@ __global__ __launch_bounds__(WTHREADS) void wino_wgrad_kernel(const WinoWgradArg
             if (ch + 1 < nchunks) { store_chunk((ch + 1) & 1); if (ch + 2 < nchunks) load_chunk(); }
         }
         __syncthreads();
+        }
     }
 
     // ---- epilogue: dw = G^T dU G per (k, c), register-local;  G^T = [[1,.5,.5,0],[0,.5,-.5,0],[0,.5,.5,1]] ----
