@@ -49,17 +49,17 @@ constexpr int WTHREADS = 512;
 // 8 channels: TWO sub-planes of ROWS x 16 bytes, pair p in sub-plane p >> 1.  An operand fragment
 // read is one ds_read_b64 per lane, lane = (row l & 15, pair l >> 4); ds_read_b64 resolves bank
 // conflicts per 32-lane half over 64 banks (= 256 bytes), and a half -- 16 rows x pairs {0, 1} or
-// {2, 3} -- then reads 256 CONTIGUOUS bytes.  With plain 32-byte rows (rounds 3's layout) a half
+// {2, 3} -- then reads 256 CONTIGUOUS bytes.  With plain 32-byte rows (round 3's layout) a half
 // read 16-byte pieces 32 bytes apart, lanes l and l + 8 on the same banks: every fragment read
 // took two LDS passes (rocprofv3: SQ_LDS_BANK_CONFLICT 80 per GPU cycle on this kernel, 0 on every
-// other one -- profiles/r04_pmc/).  The writers (8-byte V stores, 16-byte U stores) land in 256- /
-// 512-byte runs either way.
+// other one -- profiles/r04_pmc/).  Measured alternatives: 32-byte rows with the pair slot XOR-ed
+// by row bit 3 (also 64 distinct banks per half, but two 128-byte pieces instead of one 256-byte
+// run): fewer counted conflicts (30 vs 45) and a SLOWER step (10.00 vs 9.75 ms) -- contiguity of
+// the read matters more than the counter.  The 16-byte U stores are assigned so that a wave writes
+// 1 KB of ONE sub-plane (row = lane): with consecutive lanes alternating between the sub-planes
+// (the global order) even and odd lanes of an 8-lane group landed on the same banks.
 template <int ROWS> __device__ __forceinline__ int plane_pos(const int r, const int p) {
     return (p >> 1) * (ROWS * 4) + r * 4 + (p & 1) * 2;
-}
-// ... and of 16-byte piece `idx` (row idx >> 1, channels 4 (idx & 1) ..) of a [ROWS][8] slice
-template <int ROWS> __device__ __forceinline__ int plane_pos4(const int idx) {
-    return (idx & 1) * (ROWS * 4) + (idx >> 1) * 4;
 }
 typedef unsigned int u32x4w __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -71,7 +71,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // K loop structure (compile-time: a run-time choice between the two bodies spills ~400 VGPRs):
 // 0 = two phases per chunk (half the waves multiply while the other half refills, then swap; two
 // barriers), 1 = one barrier per chunk (every wave multiplies chunk ch, then stores its part of
-// chunk ch + 1 into the other stage).  tools/wino_dbg.sh builds the other variant for A/B.
+// chunk ch + 1 into the other stage; measured 6 % slower on the step, profiles/r04_negative_results.log)
 #ifndef CILRS_WINO_ONE_PHASE
 #define CILRS_WINO_ONE_PHASE 0
 #endif
@@ -207,6 +207,9 @@ __device__ __forceinline__ void wino_full_body(const WinoArgs& a, float* smem, c
     // ---- gather role (waves 0-3, one per SIMD): this thread's (tile, channel PAIR) and the 16
     //      patch pixels; 8-byte loads, packed additions, 8-byte LDS stores ----
     const bool gatherer = tid < 256;
+    // (lane = (tile l >> 2, channel pair l & 3): four adjacent lanes fetch one pixel's 32 bytes.  With
+    //  lane = (tile l & 15, pair l >> 4) the V stores of a half-wave become one 256-byte run -- fewer
+    //  LDS conflicts, 38 -> 32 per cycle -- but the patch loads coalesce worse: step 9.75 -> 10.26 ms)
     const int g_tile = (tid >> 2) & 63, g_p = tid & 3;
     unsigned voff[16];
     {
@@ -228,7 +231,7 @@ __device__ __forceinline__ void wino_full_body(const WinoArgs& a, float* smem, c
         (void*)a.U, 0, (int)(unsigned)((size_t)16 * a.C * a.K * 4), 0x00020000);
     // U chunk: thread handles 4 float4: xi = 4 pass + (tid >> 7), float4 index tid & 127 of the
     // xi's contiguous [64 k][8 c] slice
-    const int u_idx = tid & 127, u_xi0 = tid >> 7;
+    const int u_row = tid & 63, u_half = (tid >> 6) & 1, u_xi0 = tid >> 7;   // 16 bytes: row, channels 4 u_half ..
 
     f32x2 d[16];
     f32x4 ur[4];
@@ -251,7 +254,7 @@ __device__ __forceinline__ void wino_full_body(const WinoArgs& a, float* smem, c
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int xi = q * 4 + u_xi0;
-            const unsigned off = (unsigned)(xi * nchunks_all * a.K * 8 + u_idx * 4) * 4u;
+            const unsigned off = (unsigned)(xi * nchunks_all * a.K * 8 + (u_row * 2 + u_half) * 4) * 4u;
             ur[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsU, (int)off, usoff, 0));
         }
     };
@@ -277,7 +280,7 @@ __device__ __forceinline__ void wino_full_body(const WinoArgs& a, float* smem, c
     auto store_u = [&](const int stage) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<f32x4*>(Us + stage * STAGE + (q * 4 + u_xi0) * (WK * WP) + plane_pos4<WK>(u_idx)) = ur[q];
+            *reinterpret_cast<f32x4*>(Us + stage * STAGE + (q * 4 + u_xi0) * (WK * WP) + u_half * (WK * 4) + u_row * 4) = ur[q];
     };
     auto store_chunk = [&](const int stage) {
         if (CILRS_WINO_DBG & 2) {
@@ -569,7 +572,7 @@ __device__ __forceinline__ void wino_q_body(const WinoArgs& a, float* smem, cons
         (void*)a.U, 0, (int)(unsigned)((size_t)16 * a.C * a.K * 4), 0x00020000);
     // U chunk = 2,048 float4: producer thread p takes float4 p + 256 j (j < 8): xi = 2 j + (p >> 7),
     // float4 p & 127 of the xi's contiguous [64 k][8 c] slice
-    const int u_idx = ptid & 127, u_xi0 = (ptid >> 7) & 1;
+    const int u_row = ptid & 63, u_half = (ptid >> 6) & 1, u_xi0 = (ptid >> 7) & 1;
     auto load_set = [&](f32x2(&d)[16], f32x4(&u)[8], const int ch) {
         const int soff = ch * WC * 4;
         if (gatherer) {
@@ -581,7 +584,7 @@ __device__ __forceinline__ void wino_q_body(const WinoArgs& a, float* smem, cons
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int xi = 2 * j + u_xi0;
-            const unsigned off = (unsigned)(xi * nchunks * a.K * 8 + u_idx * 4) * 4u;
+            const unsigned off = (unsigned)(xi * nchunks * a.K * 8 + (u_row * 2 + u_half) * 4) * 4u;
             u[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsU, (int)off, usoff, 0));
         }
     };
@@ -610,7 +613,7 @@ __device__ __forceinline__ void wino_q_body(const WinoArgs& a, float* smem, cons
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            *reinterpret_cast<f32x4*>(Us + stage * QSTAGE + (2 * j + u_xi0) * (WK * WP) + plane_pos4<WK>(u_idx)) = u[j];
+            *reinterpret_cast<f32x4*>(Us + stage * QSTAGE + (2 * j + u_xi0) * (WK * WP) + u_half * (WK * 4) + u_row * 4) = u[j];
     };
 
     // ---- consumers: rows = 16 channels (k0 + 16 wave ..), columns = the 16 tiles ----
