@@ -740,15 +740,16 @@ def main():
             return {"workload": tag, "frames_per_s": round(b / dtb, 1),
                     "ms_per_step": round(dtb * 1e3, 3), "dtype": "bf16 operands, f32 accumulate",
                     "final_loss": round(lb["total"], 6),
-                    "roofline": {"kernel": "conv_f16_kernel<bf16, TRAIN> + wgrad_f16_kernel<bf16> "
-                                           "(forward, data gradient, weight gradient of the trunk)",
+                    "roofline": {"kernel": "conv_f16_kernel<bf16, TRAIN> / conv16p_kernel<bf16> + "
+                                           "wgrad_f16_kernel<bf16> (forward, data gradient, weight "
+                                           "gradient of the trunk; 16-bit tensors end to end)",
                                  "bound": "mfma", "achieved": round(cflb / max(cmsb, 1e-9) / 1e9, 1),
                                  "peak": 2500.0, "unit": "TFLOP/s",
                                  "frac": round(cflb / max(cmsb, 1e-9) / 1e9 / 2500.0, 4),
                                  "launches_per_step": int(sum(v["calls"] for v in convb) // 2),
-                                 "note": "hipEvent brackets of the serialised step; the fp32 "
-                                         "BatchNorm passes around the GEMMs are HBM-bound and are "
-                                         "listed in device_ms_by_kernel"},
+                                 "note": "hipEvent brackets of the serialised step; the BatchNorm "
+                                         "passes around the GEMMs (bf16 tensors, at the HBM / "
+                                         "Infinity-Cache rate) are listed in device_ms_by_kernel"},
                     "device_ms_by_kernel": {k: round(v["ms"] / 2, 3) for k, v in
                                             sorted(tb.items(), key=lambda kv: -kv[1]["ms"])[:12]}}
         torch.manual_seed(0)
