@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_serial
 rm -rf $OUT; mkdir -p $OUT
 export CILRS_OVERLAP=0
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-infer > $OUT/bench_line.json 2> $OUT/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-infer --no-loader > $OUT/bench_line.json 2> $OUT/bench.err
 f=$(find $OUT/kt -name '*kernel_stats.csv' | head -1)
 cp "$f" $OUT/kernel_stats.csv
 head -40 $OUT/kernel_stats.csv | cut -c1-200
