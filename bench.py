@@ -201,6 +201,8 @@ def main():
     ap.add_argument("--no-infer", action="store_true")
     ap.add_argument("--no-loader", action="store_true",
                     help="skip the input-pipeline leg (JPEG decode pool -> augmentation -> train step)")
+    ap.add_argument("--two-call-step", action="store_true",
+                    help="backward, then one Adam launch (A/B of cilrs_net_backward_step's per-segment Adam)")
     ap.add_argument("--force-dp", action="store_true",
                     help="use the bucketed all-reduce path even with one rank (rehearsal)")
     ap.add_argument("--rehearse", action="store_true",
@@ -252,6 +254,8 @@ def main():
     cfg = CONFIG_A if args.config == "A" else TrainConfig(**{**CONFIG_B.__dict__})
     model = CILRS(4, dropout=cfg.dropout).to(dev)
     trainer = Trainer(model, cfg, process_group=pg)
+    if args.two_call_step:
+        trainer.fuse_optimizer = False
     if pg is not None:
         broadcast_parameters(trainer.eng, pg)
     batch, u8 = synthetic_batch(args.batch, 1 + rank, dev)
@@ -451,10 +455,16 @@ def main():
         pc_ = torch.zeros(args.batch, 3, device=dev)
         ps_ = torch.zeros(args.batch, device=dev)
         ms_loss = timed(lambda: trainer.loss(pc_, batch[3], ps_, batch[1]))
-        out["kernels"]["adam" + ("+sqnorm" if cfg.grad_clip > 0 else "")] = {
-            "calls_per_step": 2 if cfg.grad_clip > 0 else 1, "ms_per_step": round(ms_adam, 4),
-            "tflops": None,
-            "gbs": round((8 if cfg.grad_clip > 0 else 7) * arena_bytes / max(ms_adam, 1e-9) / 1e6, 1)}
+        if "adam" in out["kernels"]:
+            # the step took cilrs_net_backward_step: its six per-segment Adam launches are already
+            # in the profile (serialised there; in the timed steps they run on the weight-gradient
+            # stream under the data gradients); the one-launch form is reported beside them
+            out["kernels"]["adam"]["one_launch_ms"] = round(ms_adam, 4)
+        else:
+            out["kernels"]["adam" + ("+sqnorm" if cfg.grad_clip > 0 else "")] = {
+                "calls_per_step": 2 if cfg.grad_clip > 0 else 1, "ms_per_step": round(ms_adam, 4),
+                "tflops": None,
+                "gbs": round((8 if cfg.grad_clip > 0 else 7) * arena_bytes / max(ms_adam, 1e-9) / 1e6, 1)}
         out["kernels"]["loss"] = {"calls_per_step": 1, "ms_per_step": round(ms_loss, 4),
                                   "tflops": None, "gbs": None}
         out["kernels_sum_ms"] = round(sum(k["ms_per_step"] for k in out["kernels"].values()), 3)

@@ -28,6 +28,13 @@ class Buffers(C.Structure):
                 ("workspace", vp)]
 
 
+class AdamArgs(C.Structure):
+    """struct cilrs_adam_args"""
+    _fields_ = [("exp_avg", vp), ("exp_avg_sq", vp), ("lr", C.c_double), ("beta1", C.c_double),
+                ("beta2", C.c_double), ("eps", C.c_double), ("weight_decay", C.c_double),
+                ("step", C.c_int64), ("grad_scale", C.c_float)]
+
+
 # symbol -> (restype, argtypes); every symbol include/cilrs_hip.h declares is listed here
 SIGNATURES = {
     "cilrs_version": (i32, []),
@@ -82,6 +89,7 @@ SIGNATURES = {
     "cilrs_net_forward_u8_bf16_graph": (i32, [vp, C.POINTER(Buffers), vp, vp, vp, vp, vp, vp]),
     "cilrs_loss_fwd_bwd": (i32, [vp, vp, vp, vp, i32, i32, c_float_p, f32, vp, vp, vp, vp]),
     "cilrs_net_backward": (i32, [vp, C.POINTER(Buffers), vp, vp, i32, i32, vp]),
+    "cilrs_net_backward_step": (i32, [vp, C.POINTER(Buffers), vp, vp, vp, vp]),
     "cilrs_segment_range": (i32, [i32, C.POINTER(sz), C.POINTER(sz)]),
     "cilrs_variant_segment_range": (i32, [i32, i32, C.POINTER(sz), C.POINTER(sz)]),
     "cilrs_sqnorm_scratch_bytes": (sz, []),

@@ -22,6 +22,10 @@ import torch
 
 from . import _lib as L
 
+import operator
+
+_VERSION_OF = operator.attrgetter("_version")
+
 SEG_NAMES = ("heads", "layer4", "layer3", "layer2", "layer1", "stem")
 
 
@@ -220,6 +224,13 @@ class Engine:
         # stay valid whatever runs next).  True: views of the arena, valid until the next backward.
         self.zero_copy_grads = False
         self.weights_epoch = 1            # bumped by every kernel-side write to params / BN buffers
+        # torch-visible in-place edits (`with torch.no_grad(): p.mul_(2)`) bump the tensors' version
+        # counters: the eval-mode `model(...)` call -- the reference's own inference call -- polls
+        # them (poll_versions), the latency paths rely on the weights_changed() contract instead
+        self._versioned = tuple(p for _n, p in named) + tuple(
+            b for m in module.modules() if isinstance(m, torch.nn.BatchNorm2d)
+            for b in (m.running_mean, m.running_var))
+        self._version_sum = sum(map(_VERSION_OF, self._versioned))
 
     # ------------------------------------------------------------------------------------------
     def is_attached(self) -> bool:
@@ -256,6 +267,19 @@ class Engine:
         place by other means while the module stays in eval mode calls CILRS.weights_changed()."""
         return (self.weights_epoch * 0xD6E8FEB86659FD93) & 0xFFFFFFFFFFFFFFFF or 1
 
+    def poll_versions(self) -> bool:
+        """Bump the weights epoch if any parameter / BatchNorm buffer was modified in place through
+        torch since the last poll (sum of the tensors' `_version` counters: ~20 us for the 250
+        tensors, so only the eval-mode `model(...)` call does it on every use; Predictor and
+        run_forward_u8 -- the latency paths -- rely on CILRS.weights_changed()).  Edits that torch
+        cannot see (`p.data`, raw pointers) always need weights_changed()."""
+        v = sum(map(_VERSION_OF, self._versioned))
+        if v == self._version_sum:
+            return False
+        self._version_sum = v
+        self.weights_epoch += 1
+        return True
+
     def _announce_weights(self, pl):
         L.check(L.lib().cilrs_net_set_weights_key(pl.handle, self.weights_key()))
 
@@ -286,6 +310,8 @@ class Engine:
         sn, sc, sh, sw = image.stride()
         if train:
             self.weights_epoch += 1           # BN running statistics are about to move
+        else:
+            self.poll_versions()
         self._announce_weights(pl)
         L.check(L.lib().cilrs_net_forward(
             pl.handle, C.byref(pl.bufs), L.ptr(image), sn, sc, sh, sw,
@@ -370,6 +396,19 @@ class Engine:
                              self.nbt.data_ptr(), pl.workspace.data_ptr())
         L.check(L.lib().cilrs_net_backward(
             pl.handle, C.byref(bufs), L.ptr(dcontrols), L.ptr(dpred_speed), seg_begin, seg_end,
+            self._stream()))
+
+    def run_backward_step(self, pl, dcontrols, dpred_speed, exp_avg, exp_avg_sq, lr, betas, eps,
+                          weight_decay, step, grad_scale=1.0):
+        """loss.backward() + Adam.step() in one library call (cilrs_net_backward_step): each
+        segment's parameter range is updated as soon as its gradients are complete, under the
+        remaining data gradients.  No gradient clipping on this path."""
+        opt = L.AdamArgs(exp_avg.data_ptr(), exp_avg_sq.data_ptr(), float(lr), float(betas[0]),
+                         float(betas[1]), float(eps), float(weight_decay), int(step),
+                         float(grad_scale))
+        self.weights_epoch += 1               # the update writes the parameter arena in place
+        L.check(L.lib().cilrs_net_backward_step(
+            pl.handle, C.byref(pl.bufs), L.ptr(dcontrols), L.ptr(dpred_speed), C.byref(opt),
             self._stream()))
 
     def grads_aliased(self) -> bool:

@@ -79,6 +79,9 @@ class Trainer:
         self._kind = 1 if cfg.loss == "l1" else 0
         self._seed_calls = 0
         self.arena_grad_scale = 1.0
+        # single-GPU steps without clipping take cilrs_net_backward_step (False: backward, then
+        # one Adam launch over the arena -- the same numbers, element by element)
+        self.fuse_optimizer = True
         self.reducer = None
         self.rank = 0
         if process_group is not None:
@@ -148,7 +151,15 @@ class Trainer:
                                                    seed)
         # `speeds` is both an input and the speed head's regression target (nb:550)
         _, dc, dp = self.loss(controls, tgts, pred_speed, speeds)
-        if self.reducer is None:
+        if self.reducer is None and self.cfg.grad_clip <= 0 and self.fuse_optimizer:
+            # backward + Adam in one call: a segment's update runs as soon as its gradients are
+            # complete (clipping needs the global norm first and keeps the two-call path below)
+            self.step_count += 1
+            self.arena_grad_scale = 1.0
+            eng.run_backward_step(pl, dc, dp, self.exp_avg, self.exp_avg_sq, self.lr,
+                                  self.cfg.betas, self.cfg.eps, self.cfg.weight_decay,
+                                  self.step_count)
+        elif self.reducer is None:
             eng.run_backward(pl, dc, dp)
             self.optimizer_step(1.0)
         else:

@@ -36,6 +36,8 @@
 // by a few 1e-6 relative, inside the 1e-4 contract (tests/test_ops_gpu.py).
 #include "common.h"
 
+#include <type_traits>
+
 namespace cilrs {
 namespace {
 
@@ -183,6 +185,15 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restri
     }
 }
 
+// PRE (launches with an addend and / or the BatchNorm-backward reductions, no channel split): the
+// epilogue's operands do not wait for the K loop to end.  The addend is loaded in the prologue and
+// planted in the accumulators -- A^T M A is linear and M[0][0], -M[0][3], -M[3][0], M[3][3] reach
+// exactly one output pixel each -- and the y / z tensors of the reductions are requested when the
+// last chunk's global loads have been consumed (their registers are free from then on; half of them:
+// the register file holds 32 more, the other half is requested right after the loop), so the
+// burst of 2 x 64 KB per block that all CUs used to issue TOGETHER after their last MFMA runs
+// under the last one and a half chunks instead.
+template <bool PRE>
 __device__ __forceinline__ void wino_full_body(const WinoArgs& a, float* smem, const int bid) {
     constexpr int STAGE = 16 * WT * WP + 16 * WK * WP;      // floats per stage (64 KB)
     float* Vs = smem;                          // [2 stages]: [16][WT][WP] | [16][WK][WP]
@@ -305,6 +316,51 @@ __device__ __forceinline__ void wino_full_body(const WinoArgs& a, float* smem, c
 #pragma unroll
         for (int m = 0; m < 2; ++m) acc[x][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // ---- epilogue coordinates: this lane's tile (one per lane) and its 2 x 4 consecutive channels ----
+    const int e_t = a.tile_begin + blk_m * WT + tg * 16 + l15;
+    const bool e_tv = e_t < total_tiles;
+    const int e_n = e_tv ? e_t / tiles_img : 0, e_rem = e_t - e_n * tiles_img;
+    const int e_ty = e_rem / TW, e_tx = e_rem - e_ty * TW;
+    const int co = k0 + kg * 32 + lq * 4;                   // + 16 mb
+    const size_t ybytes = (size_t)a.N * a.H * a.W * a.K * 4;
+    const int yrec = (int)(unsigned)ybytes;
+    unsigned yoff[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int oy = 2 * e_ty + (q >> 1), ox = 2 * e_tx + (q & 1);
+        const bool ok = e_tv && oy < a.H && ox < a.W;
+        yoff[q] = ok ? (unsigned)((((e_n * a.H + oy) * a.W + ox) * a.K + co) * 4) : 0xFFFFFFFFu;
+    }
+    // (a tensor the launch does not have gets a zero-length buffer: its loads return zeros and
+    //  cost no traffic, so every load below is issued and consumed unconditionally)
+    f32x4 zz[2][4], yy[2][4];
+    auto prefetch_epilogue = [&](const int mb) {     // (one 16-channel half: 32 registers)
+        const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(a.bwd_z ? a.bwd_z : a.y), 0, (a.bwd_partial && a.bwd_relu) ? yrec : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(a.bwd_y ? a.bwd_y : a.y), 0, a.bwd_partial ? yrec : 0, 0x00020000);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            zz[mb][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsZ, (int)yoff[q], mb * 64, 0));
+            yy[mb][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)yoff[q], mb * 64, 0));
+        }
+    };
+    if constexpr (PRE) {
+        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(a.addend ? a.addend : a.y), 0, a.addend ? yrec : 0, 0x00020000);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            f32x4 ad[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                ad[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)yoff[q], mb * 64, 0));
+            acc[0][mb] = ad[0];          // M[0][0] -> Y[0][0]
+            acc[3][mb] = -ad[1];         // M[0][3] -> -Y[0][1]
+            acc[12][mb] = -ad[2];        // M[3][0] -> -Y[1][0]
+            acc[15][mb] = ad[3];         // M[3][3] -> Y[1][1]
+        }
+    }
+
     const long long tm_start = (a.stamps != nullptr && bid == 0) ? __builtin_amdgcn_s_memtime() : 0;
     load_chunk(0);
     store_chunk(0);
@@ -351,10 +407,19 @@ __device__ __forceinline__ void wino_full_body(const WinoArgs& a, float* smem, c
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                      // then 4 MFMAs
         }
     };
-    auto refill = [&](const int ch) {                   // chunk ch + 1 into the other stage
-        if (ch + 1 < nchunks) {
+    // chunk ch + 1 into the other stage.  KIND (compile time): 0 = a chunk with two successors
+    // (store ch + 1, request ch + 2), 1 = the second to last (store the last chunk; PRE: request the
+    // epilogue's operands into the chunk registers, which are dead from here on), 2 = the last.
+    // The last two chunks are peeled out of the loop: inside it the compiler would have to keep the
+    // prefetched operands AND the chunk registers alive together (+64 registers = spills).
+    auto refill = [&](const int ch, auto kind) {
+        constexpr int KIND = decltype(kind)::value;
+        if constexpr (KIND == 0) {
             store_chunk((ch + 1) & 1);
-            if (ch + 2 < nchunks) load_chunk(ch + 2);
+            load_chunk(ch + 2);
+        } else if constexpr (KIND == 1) {
+            store_chunk((ch + 1) & 1);
+            if constexpr (PRE) prefetch_epilogue(0);
         }
     };
     // Two phases per chunk, a barrier after each: waves 0-3 multiply while waves 4-7 store their
@@ -373,7 +438,7 @@ __device__ __forceinline__ void wino_full_body(const WinoArgs& a, float* smem, c
     const long long tm0 = tm_start;
     long long tm_loop0 = 0;
     if (stamp) tm_loop0 = __builtin_amdgcn_s_memtime();
-    for (int ch = 0; ch < nchunks; ++ch) {
+    auto chunk_step = [&](const int ch, auto kind) {
         long long ta = 0, tb = 0, tc = 0;
         if (stamp) ta = __builtin_amdgcn_s_memtime();
         if constexpr (CILRS_WINO_ONE_PHASE != 0) {
@@ -381,58 +446,55 @@ __device__ __forceinline__ void wino_full_body(const WinoArgs& a, float* smem, c
             // part of chunk ch + 1 into the OTHER stage -- nobody reads that stage before the
             // barrier, and nobody overwrites stage ch & 1 before every wave has passed it
             multiply(ch);
-            refill(ch);
+            refill(ch, kind);
             if (stamp) tb = tc = __builtin_amdgcn_s_memtime();
             __syncthreads();
             if (stamp) { tm_a += tb - ta; tm_bar += __builtin_amdgcn_s_memtime() - tc; }
-            continue;
         } else {
-        if (late) {
-            refill(ch);
-            __builtin_amdgcn_sched_barrier(0);
+            if (late) {
+                refill(ch, kind);
+                __builtin_amdgcn_sched_barrier(0);
+                __syncthreads();
+                if (stamp) tb = __builtin_amdgcn_s_memtime();
+                multiply(ch);
+            } else {
+                multiply(ch);
+                __builtin_amdgcn_sched_barrier(0);
+                __syncthreads();
+                if (stamp) tb = __builtin_amdgcn_s_memtime();
+                refill(ch, kind);
+            }
+            if (stamp) tc = __builtin_amdgcn_s_memtime();
             __syncthreads();
-            if (stamp) tb = __builtin_amdgcn_s_memtime();
-            multiply(ch);
-        } else {
-            multiply(ch);
-            __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();
-            if (stamp) tb = __builtin_amdgcn_s_memtime();
-            refill(ch);
+            if (stamp) {
+                tm_a += tb - ta;
+                tm_b += tc - tb;
+                tm_bar += __builtin_amdgcn_s_memtime() - tc;
+            }
         }
-        if (stamp) tc = __builtin_amdgcn_s_memtime();
-        __syncthreads();
-        if (stamp) {
-            tm_a += tb - ta;
-            tm_b += tc - tb;
-            tm_bar += __builtin_amdgcn_s_memtime() - tc;
+    };
+    {
+        int ch = 0;
+        for (; ch + 2 < nchunks; ++ch) chunk_step(ch, std::integral_constant<int, 0>{});
+        if (nchunks >= 2) {
+            chunk_step(ch, std::integral_constant<int, 1>{});
+            ++ch;
+        } else if constexpr (PRE) {
+            prefetch_epilogue(0);
         }
-        }
+        if (nchunks >= 1) chunk_step(ch, std::integral_constant<int, 2>{});
     }
     const long long tm_loop1 = stamp ? __builtin_amdgcn_s_memtime() : 0;
 
-    // ---- epilogue: this lane's tile (one per lane) and its 2 x 4 consecutive channels ----
-    const int t = a.tile_begin + blk_m * WT + tg * 16 + l15;
-    const bool tv = t < total_tiles;
-    const int n = tv ? t / tiles_img : 0, rem = t - n * tiles_img;
-    const int ty = rem / TW, tx = rem - ty * TW;
-    const int co = k0 + kg * 32 + lq * 4;                   // + 16 mb
-    const size_t ybytes = (size_t)a.N * a.H * a.W * a.K * 4;
-    const int yrec = (int)(unsigned)ybytes;
+    // ---- epilogue ----
+    if constexpr (PRE) prefetch_epilogue(1);      // the second half's operands under the first half's transform
     // channel split: this block's partial result goes to slab `part`, raw (the reduce launch adds
     // the addend and takes the column partials of the finished tensor)
     const bool split = csplit > 1;
     float* const ydst = split ? a.slabs + (size_t)part * (ybytes / 4) : a.y;
     const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)ydst, 0, yrec, 0x00020000);
-    unsigned yoff[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int oy = 2 * ty + (q >> 1), ox = 2 * tx + (q & 1);
-        const bool ok = tv && oy < a.H && ox < a.W;
-        yoff[q] = ok ? (unsigned)((((n * a.H + oy) * a.W + ox) * a.K + co) * 4) : 0xFFFFFFFFu;
-    }
     const bool stats_fwd = !split && a.bn_partial != nullptr, stats_bwd = !split && a.bwd_partial != nullptr;
-    const bool with_add = !split && a.addend != nullptr;
+    const bool with_add = !PRE && !split && a.addend != nullptr;
     f32x4 ad[2][4];
     if (with_add) {
         const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)a.addend, 0, yrec, 0x00020000);
@@ -474,22 +536,28 @@ __device__ __forceinline__ void wino_full_body(const WinoArgs& a, float* smem, c
                 cs2[mb] += v * v;
             }
         } else if (stats_bwd) {
-            const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc((void*)a.bwd_z, 0, yrec, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.bwd_y, 0, yrec, 0x00020000);
             const f32x4 bmean = *reinterpret_cast<const f32x4*>(a.bwd_stats + co + mb * 16);
             const f32x4 brstd = *reinterpret_cast<const f32x4*>(a.bwd_stats + a.K + co + mb * 16);
+            if constexpr (!PRE) {
+                const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc((void*)a.bwd_z, 0, yrec, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)a.bwd_y, 0, yrec, 0x00020000);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    zz[mb][q] = f32x4{1.f, 1.f, 1.f, 1.f};
+                    if (a.bwd_relu)
+                        zz[mb][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsZ, (int)yoff[q], mb * 64, 0));
+                    yy[mb][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)yoff[q], mb * 64, 0));
+                }
+            }
+            const bool relu = a.bwd_relu != 0;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                f32x4 zz = f32x4{1.f, 1.f, 1.f, 1.f};
-                if (a.bwd_relu)
-                    zz = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsZ, (int)yoff[q], mb * 64, 0));
-                const f32x4 yy = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)yoff[q], mb * 64, 0));
                 const bool ok = yoff[q] != 0xFFFFFFFFu;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float g = (ok && zz[e] > 0.f) ? y[q][e] : 0.f;
+                    const float g = (ok && (!relu || zz[mb][q][e] > 0.f)) ? y[q][e] : 0.f;
                     cs1[mb][e] += g;
-                    cs2[mb][e] = fmaf(g, (yy[e] - bmean[e]) * brstd[e], cs2[mb][e]);
+                    cs2[mb][e] = fmaf(g, (yy[mb][q][e] - bmean[e]) * brstd[e], cs2[mb][e]);
                 }
             }
         }
@@ -770,10 +838,11 @@ __device__ __forceinline__ void wino_q_body(const WinoArgs& a, float* smem, cons
 // One launch = the 64-tile blocks followed by the 16-tile tail blocks: the tail is dispatched as the
 // CUs of the last full round drain, with no kernel boundary (and, in the overlapped backward pass, no
 // extra event dependency) in between.
+template <bool PRE>
 __global__ __launch_bounds__(WTHREADS) void conv_wino_kernel(const WinoArgs a, const WinoArgs tail,
                                                              const int nfull) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    if ((int)blockIdx.x < nfull) wino_full_body(a, smem, (int)blockIdx.x);
+    if ((int)blockIdx.x < nfull) wino_full_body<PRE>(a, smem, (int)blockIdx.x);
     else wino_q_body(tail, smem, (int)blockIdx.x - nfull);
 }
 
@@ -1022,8 +1091,10 @@ constexpr size_t kWinoLds = (size_t)2 * (16 * WT * WP + 16 * WK * WP) * sizeof(f
 // (a plan calls this when it is built: the attribute must not be set for the first time inside a
 //  stream capture)
 int wino_prepare() {
-    if (once_per_device(reinterpret_cast<const void*>(&conv_wino_kernel))) {
-        CILRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel),
+    if (once_per_device(reinterpret_cast<const void*>(&conv_wino_kernel<false>))) {
+        CILRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoLds));
+        CILRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWinoLds));
     }
     return 0;
@@ -1093,7 +1164,7 @@ int launch_conv_wino(const WinoArgs& a_in, hipStream_t s) {
         // every tile on the 64-tile kernel, csplit blocks per tile; then the fixed-order reduce
         a.tile_begin = 0; a.row0 = 0; a.rows = 0;
         const int nfull = wino_groups(a.N, a.H, a.W) * (a.K / WK) * a.csplit;
-        conv_wino_kernel<<<nfull, WTHREADS, kWinoLds, s>>>(a, a, nfull);
+        conv_wino_kernel<false><<<nfull, WTHREADS, kWinoLds, s>>>(a, a, nfull);
         CILRS_LAUNCH_CHECK();
         const int mode = a.bwd_partial ? 1 : 0;
         float* partial = a.bwd_partial ? a.bwd_partial : a.bn_partial ? a.bn_partial : a.scratch_partial;
@@ -1106,7 +1177,11 @@ int launch_conv_wino(const WinoArgs& a_in, hipStream_t s) {
     a.tile_begin = 0; a.row0 = 0;
     t.tile_begin = sp.full * WT; t.row0 = sp.full; t.stamps = nullptr;
     const int nfull = sp.full * (a.K / WK), ntail = sp.tail * (a.K / WK);
-    conv_wino_kernel<<<nfull + ntail, WTHREADS, nfull > 0 ? kWinoLds : kWinoQLds, s>>>(a, t, nfull);
+    // (operands of the epilogue requested ahead of the K loop's end: wino_full_body<true>)
+    if (a.addend || a.bwd_partial)
+        conv_wino_kernel<true><<<nfull + ntail, WTHREADS, nfull > 0 ? kWinoLds : kWinoQLds, s>>>(a, t, nfull);
+    else
+        conv_wino_kernel<false><<<nfull + ntail, WTHREADS, nfull > 0 ? kWinoLds : kWinoQLds, s>>>(a, t, nfull);
     CILRS_LAUNCH_CHECK();
     return 0;
 }

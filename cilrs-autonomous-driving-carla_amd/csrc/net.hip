@@ -289,6 +289,7 @@ static int dy_ring_depth() {
 
 struct cilrs_net {
     const Arch* A = nullptr;               // architecture variant of this plan
+    const cilrs_adam_args* fused_adam = nullptr;   // set for the duration of cilrs_net_backward_step
     int B, H, W;
     std::vector<ConvG> cg;                 // geometry + workspace offsets (floats) per conv
     int H0, W0, H1, W1;                    // stem conv out, maxpool out
@@ -2046,6 +2047,24 @@ int cilrs_net_backward(cilrs_net* net, const cilrs_buffers* bufs, const float* d
     float* Gp = bufs->grads;
     const int B = net->B;
     auto last_conv = [&](const BlockT& blk) { return blk.conv3 >= 0 ? blk.conv3 : blk.conv2; };
+    // cilrs_net_backward_step: segment `seg`'s gradients are complete once the main stream reaches
+    // this point (BatchNorm / head gradients) and the side stream has run what it holds (weight
+    // gradients): its Adam update goes on the side stream behind both
+    auto segment_done = [&](int seg) -> int {
+        const cilrs_adam_args* o = net->fused_adam;
+        if (!o) return 0;
+        const size_t b = A.seg_begin[seg], n = A.seg_end[seg] - A.seg_begin[seg];
+        hipStream_t st = s;
+        if (use_overlap(net)) {
+            if (gbuf_side_begin(net, s)) return 1;       // side waits for the main stream's part
+            st = net->side[0];
+        }
+        RUN(net, "adam", 0.0, 28.0 * n, st,
+            launch_adam(bufs->params + b, Gp + b, o->exp_avg + b, o->exp_avg_sq + b, n, o->lr,
+                        o->beta1, o->beta2, o->eps, o->weight_decay, (long long)o->step, nullptr,
+                        o->grad_scale, st));
+        return 0;
+    };
 
     for (int seg = seg_begin; seg < seg_end; ++seg) {
         if (seg == 0) {
@@ -2061,6 +2080,7 @@ int cilrs_net_backward(cilrs_net* net, const cilrs_buffers* bufs, const float* d
                 RUN(net, "heads_bwd", 0.0, 0.0, s,
                     launch_avgpool_bwd(ws + net->dcombined, ws + net->G[3], B, net->featHW, A.feat,
                                        A.feat + 128, s));
+            if (segment_done(seg)) return 1;
             continue;
         }
         if (seg >= 1 && seg <= 4) {
@@ -2185,8 +2205,10 @@ int cilrs_net_backward(cilrs_net* net, const cilrs_buffers* bufs, const float* d
                     if (dgrad(blk.down, gdn, 3, 3, nullptr, nullptr, bi == 0)) return 1;
                 }
             }
-            // the segment's weight gradients are complete when this call returns its work
-            if (gbuf_join_all(net, s)) return 1;
+            // (the segment's weight gradients are complete when this call returns its work: the
+            //  side stream joins at the end of the call -- between the segments of ONE call the
+            //  data-gradient chain does not wait for the weight gradients any more)
+            if (segment_done(seg)) return 1;
             continue;
         }
         // seg == 5: stem.  G[3] holds d(maxpool output)
@@ -2197,15 +2219,40 @@ int cilrs_net_backward(cilrs_net* net, const cilrs_buffers* bufs, const float* d
             const unsigned char* argmax =
                 reinterpret_cast<const unsigned char*>(bufs->workspace) + net->argmax_b;
             // max-pool backward + ReLU mask are rebuilt inside the BatchNorm-backward passes
+            if (gbuf_acquire(net, s, 1)) return 1;           // G[1] is rewritten below
             RUN(net, "bn_bwd.stem", 0.0, 4.0 * g0.M * 64 * 3.0, s,
                 launch_bn_bwd_pool(ws + net->G[3], argmax, ws + g0.y, B, net->H0, net->W0, 64,
                                    P + b0.gamma, ws + g0.stats, Gp + b0.gamma, Gp + b0.beta,
                                    ws + net->bn_coef, ws + net->bn_partial, ws + net->G[1], s));
             if (conv_wgrad(net, c0, g0, ws + net->x4, 4, ws + net->G[1], Gp + c0.w, ws, s))
                 return 1;
+            if (segment_done(seg)) return 1;
         }
     }
+    // everything the side stream still runs (weight gradients, fused Adam launches) joins here
+    if (gbuf_join_all(net, s)) return 1;
+    if (net->fused_adam && use_overlap(net)) {
+        CILRS_HIP(hipEventRecord(net->fork_ev, net->side[0]));
+        CILRS_HIP(hipStreamWaitEvent(s, net->fork_ev, 0));
+    }
     return 0;
+}
+
+// Backward of every segment with torch.optim.Adam.step() (notebook/notebook.ipynb:555) fused in:
+// the update of a segment's parameter range is enqueued -- on the weight-gradient stream, behind
+// that segment's weight gradients -- as soon as the segment's gradients are complete, so the
+// HBM-bound update of layer4 (13 M of the 21 M parameters) runs under the matrix-pipe-bound data
+// gradients of layers 3..1 instead of after the stem.  Same arithmetic per element as
+// cilrs_adam_step over the whole arena (no gradient clipping: the global norm needs every
+// gradient first -- callers that clip use cilrs_net_backward + cilrs_grad_sqnorm + cilrs_adam_step).
+int cilrs_net_backward_step(cilrs_net* net, const cilrs_buffers* bufs, const float* dcontrols,
+                            const float* dpred_speed, const cilrs_adam_args* opt, void* stream) {
+    CILRS_CHECK(net && opt && opt->exp_avg && opt->exp_avg_sq, "backward_step: NULL argument");
+    CILRS_CHECK(opt->step >= 1, "backward_step: step must be >= 1");
+    net->fused_adam = opt;
+    const int rc = cilrs_net_backward(net, bufs, dcontrols, dpred_speed, 0, 6, stream);
+    net->fused_adam = nullptr;
+    return rc;
 }
 
 static int backward_heads(cilrs_net* net, const cilrs_buffers* bufs, const float* dcontrols,

@@ -294,6 +294,24 @@ int cilrs_adam_step(float* params, const float* grads, float* exp_avg, float* ex
                     void* stream);
 int cilrs_scale(float* x, size_t n, const float* clip_out2, float c, void* stream);
 
+/* loss.backward() + optimizer.step() (notebook/notebook.ipynb:552, 555) in ONE call for steps
+ * without gradient clipping: cilrs_net_backward over all six segments, and the Adam update of a
+ * segment's parameter range enqueued as soon as that segment's gradients are complete (on the
+ * plan's weight-gradient stream, so the HBM-bound update of layer4's 13 M parameters runs under
+ * the data gradients of layers 3..1).  Same arithmetic per element as cilrs_adam_step; when the
+ * call returns its work to `stream`, parameters, moments and gradients are final.  A step that
+ * clips (nb:553-554) needs the global norm first: cilrs_net_backward + cilrs_grad_sqnorm +
+ * cilrs_adam_step. */
+typedef struct {
+    float* exp_avg;         /* arena-shaped first / second moments                     */
+    float* exp_avg_sq;
+    double lr, beta1, beta2, eps, weight_decay;
+    int64_t step;           /* 1-based step count                                       */
+    float grad_scale;       /* multiplies the gradients (1 / world_size for summed DP gradients) */
+} cilrs_adam_args;
+int cilrs_net_backward_step(cilrs_net* net, const cilrs_buffers* bufs, const float* dcontrols,
+                            const float* dpred_speed, const cilrs_adam_args* opt, void* stream);
+
 /* ---- training input pipeline on the device ------------------------------------
  * The reference's per-frame CPU augmentation (albumentations Compose, notebook/notebook.ipynb:387-394:
  * RandomBrightnessContrast p.5, HueSaturationValue p.3, GaussianBlur p.2, GaussNoise p.3,

@@ -800,6 +800,33 @@ def _dropout_masks(B, p, seed):
     return masks
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_fused_backward_and_adam_equals_the_two_call_step(precision):
+    """cilrs_net_backward_step (a segment's Adam update enqueued as soon as its gradients are
+    complete, on the weight-gradient stream) against cilrs_net_backward + ONE cilrs_adam_step over
+    the arena: the same numbers element by element -- parameters, both moments, BatchNorm buffers
+    and the gradient arena -- after three steps, and the losses along the way."""
+    from cilrs_mi355 import CONFIG_A, Trainer
+    batches = [to_dev(*O.synthetic_batch(16, seed=40 + i)[:4]) for i in range(3)]
+    out = []
+    for fused in (True, False):
+        m = make_model(seed=5)
+        tr = Trainer(m, CONFIG_A, precision=precision)
+        tr.fuse_optimizer = fused
+        losses = []
+        for b in batches:
+            tr.train_step(*b)
+            losses.append(tr.losses()["total"])
+        torch.cuda.synchronize()
+        eng = m.engine()
+        out.append((losses, eng.params.clone(), tr.exp_avg.clone(), tr.exp_avg_sq.clone(),
+                    eng.bn.clone(), eng.grads.clone(), tr.step_count))
+    a, b = out
+    assert a[0] == b[0] and a[6] == b[6] == 3
+    for x, y in zip(a[1:6], b[1:6]):
+        assert torch.equal(x, y)
+
+
 def test_dropout_train_step_matches_oracle_under_the_same_masks():
     """Config B as the notebook executed it (dropout 0.5, notebook/notebook.ipynb:480, 549-555).
     torch's CPU RNG stream cannot be reproduced on the device, so parity is functional: the masks
@@ -1140,8 +1167,8 @@ def test_inference_state_cache_follows_weight_updates():
     """The plan keeps what it derives from the weights for inference (eval-mode BatchNorm
     scale/shift, padded stem weights, 16-bit folded weights) between calls; every way the weights
     can change must invalidate it: load_state_dict, a fused train step, a torch.optim step through
-    the autograd bridge, and CILRS.weights_changed() after a raw in-place edit -- on the eager and
-    the hipGraph paths, fp32 and fp16."""
+    the autograd bridge, CILRS.weights_changed() after a raw in-place edit -- on the eager and
+    the hipGraph paths, fp32 and fp16 -- and the version-counter poll of the bare eval-mode call."""
     from cilrs_mi355 import CONFIG_A, Trainer
     from cilrs_mi355.predict import Predictor
     frame = np.floor(O._hash_u01(3, 9, 88 * 200 * 3) * 256).astype(np.uint8).reshape(88, 200, 3)
@@ -1182,6 +1209,21 @@ def test_inference_state_cache_follows_weight_updates():
             m.weights_changed()
             a4 = pr.predict_controls(frame, 30.0, 1)
             assert abs((a4[3] - a3[3]) - 0.25 * 90.0) <= 1e-3 and a4[:3] == a3[:3]
+            # 5. the reference's own inference call -- eval-mode `model(img, speed, command)` --
+            #    polls the tensors' version counters: a torch-visible in-place edit needs no
+            #    notification there (the latency paths above rely on weights_changed())
+            m.eval()
+            with torch.no_grad():
+                b0 = m(imgs, spds, cmds)[0].clone()
+                m.visual_encoder[4][0].bn1.weight.mul_(1.5)
+                m.visual_encoder[4][0].bn1.running_mean.add_(0.125)
+                b1 = m(imgs, spds, cmds)[0].clone()
+            m2 = make_model()
+            m2.load_state_dict(m.state_dict(), strict=True)
+            m2.eval()
+            with torch.no_grad():
+                want = m2(imgs, spds, cmds)[0]
+            assert not torch.equal(b0, b1) and torch.equal(b1, want)
 
 
 def test_concurrent_inference_lanes_match_the_single_plan():
