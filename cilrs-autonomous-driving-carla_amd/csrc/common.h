@@ -538,6 +538,12 @@ int launch_f32_to_f16(const float* x, void* y, size_t n, int bf16, hipStream_t s
 int launch_avgpool_f16(const void* x, float* out, int N, int HW, int C, int out_ld, int bf16,
                        hipStream_t s);
 
+// fp32 stem of the training step (stem_f32.hip): conv 7x7/s2 on the channel-padded image with the
+// weights in registers and k = 7 x (21 + 1); bn_partial [2][64][stem_f32_rows()] or NULL.
+// stem_f32_rows() == 0: geometry not served (callers keep the implicit GEMM)
+int stem_f32_rows(int N, int H, int W);
+int launch_stem_f32(const float* x4, const float* w, float* y, float* bn_partial, int N, int H, int W,
+                    hipStream_t s);
 // 16-bit stem of the serving path (stem_f16.hip): conv 7x7/s2 + folded BN + ReLU on the channel-
 // padded fp32 image -> 16-bit [N][Ho][Wo][64]; max-pool 3x3/s2/p1 on 16-bit NHWC
 int launch_fold_stem_f16(const float* w, const float* stats, void* w16, float* bias, int bf16,

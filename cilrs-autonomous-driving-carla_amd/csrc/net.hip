@@ -1178,8 +1178,17 @@ static int forward_from_x4(cilrs_net* net, const cilrs_buffers* bufs, const floa
     const float* cur;
     if (train) {
         int nb = 0;                             // batch statistics fused into the conv epilogue
-        if (conv_fwd(net, A.convs[0], net->cg[0], ws + net->x4, 4, ws + net->w4,
-                     ws + net->cg[0].y, ws, s, &nb)) return 1;
+        if (const int srows = stem_f32_rows(B, net->H, net->W)) {
+            // (weights in registers, k = 7 x 22 instead of 13 x 16: stem_f32.hip)
+            RUN(net, "conv_fwd.stem", 2.0 * net->cg[0].M * 64 * 147,
+                16.0 * B * net->H * net->W + 4.0 * net->cg[0].M * 64, s,
+                launch_stem_f32(ws + net->x4, P + A.convs[0].w, ws + net->cg[0].y,
+                                ws + net->bn_partial, B, net->H, net->W, s));
+            nb = srows;
+        } else if (conv_fwd(net, A.convs[0], net->cg[0], ws + net->x4, 4, ws + net->w4,
+                            ws + net->cg[0].y, ws, s, &nb)) {
+            return 1;
+        }
         // stem BatchNorm: statistics only -- its apply + ReLU is fused into the max-pool, the
         // post-BN tensor (144 MB at B=128) is never written
         {
@@ -2377,6 +2386,15 @@ int cilrs_adam_step(float* params, const float* grads, float* exp_avg, float* ex
     return launch_adam(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay,
                        (long long)step, clip_out2, grad_scale,
                        reinterpret_cast<hipStream_t>(stream));
+}
+
+int cilrs_stem_conv_fwd(const float* x4, const float* w, float* y, float* bn_partial, int N, int H,
+                        int W, int* partial_rows, void* stream) {
+    CILRS_CHECK(x4 && w && y, "stem_conv_fwd: NULL argument");
+    const int rows = stem_f32_rows(N, H, W);
+    CILRS_CHECK(rows > 0, "stem_conv_fwd: geometry %dx%dx%d not served", N, H, W);
+    if (partial_rows) *partial_rows = rows;
+    return launch_stem_f32(x4, w, y, bn_partial, N, H, W, reinterpret_cast<hipStream_t>(stream));
 }
 
 int cilrs_scale(float* x, size_t n, const float* clip_out2, float c, void* stream) {

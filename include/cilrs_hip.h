@@ -294,6 +294,14 @@ int cilrs_adam_step(float* params, const float* grads, float* exp_avg, float* ex
                     void* stream);
 int cilrs_scale(float* x, size_t n, const float* clip_out2, float c, void* stream);
 
+/* op-level stem convolution of the TRAINING step (visual_encoder.0 = torchvision resnet34.conv1,
+ * model/autonomous_drive.py:366; trained by notebook/notebook.ipynb:549-555): conv 7x7 / stride 2 /
+ * pad 3, fp32, x4 = the channel-padded NHWC image [N,H,W,4], w = OHWI [64,7,7,3], y = [N,Ho,Wo,64];
+ * bn_partial (may be NULL) receives the [2][64][*partial_rows] column partials (sum, sum of
+ * squares) the following BatchNorm reduces.  Widths up to 445 pixels. */
+int cilrs_stem_conv_fwd(const float* x4, const float* w, float* y, float* bn_partial, int N, int H,
+                        int W, int* partial_rows, void* stream);
+
 /* loss.backward() + optimizer.step() (notebook/notebook.ipynb:552, 555) in ONE call for steps
  * without gradient clipping: cilrs_net_backward over all six segments, and the Adam update of a
  * segment's parameter range enqueued as soon as that segment's gradients are complete (on the

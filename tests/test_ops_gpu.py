@@ -130,6 +130,48 @@ def test_conv_dgrad(case, cfg, splitk, with_addend):
     assert (got - want).abs().max() <= _tol(want)
 
 
+@pytest.mark.parametrize("shape", [(5, 88, 200), (3, 176, 400), (2, 30, 70), (1, 88, 200), (3, 9, 253),
+                                   (2, 61, 445)])
+def test_stem_conv_fwd_with_batch_statistics(shape):
+    """cilrs_stem_conv_fwd (csrc/stem_f32.hip: conv 7x7 / stride 2 / pad 3 of the training step, the
+    weights in registers, k = 7 x 22) against torch's conv2d on the CPU, and its per-tile column
+    partials against the sums of its own output: the reference's frame size, the ResNet-50 variant's,
+    odd sizes with partial last tiles, rows that end inside / at the edge of a 64-pixel DMA segment
+    and the widest rows either row pitch serves."""
+    L = _lib()
+    lib = L.lib()
+    N, H, W = shape
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(N, 3, H, W, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) / 147 ** 0.5
+    ref = F.conv2d(x.double(), w.double(), None, 2, 3)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    x4 = torch.zeros(N, H, W, 4)
+    x4[..., :3] = x.permute(0, 2, 3, 1)
+    x4[..., 3] = 7.0                                 # (the pad channel must never reach the result)
+    x4 = x4.cuda()
+    y = torch.full((N, Ho, Wo, 64), float("nan"), device="cuda")
+    rows = C.c_int(0)
+    part = torch.full((2 * 64 * (N * Ho * Wo // 64 + 64),), float("nan"), device="cuda")
+    L.check(lib.cilrs_stem_conv_fwd(L.ptr(x4), L.ptr(ohwi(w)), L.ptr(y), L.ptr(part), N, H, W,
+                                    C.byref(rows), stream()))
+    torch.cuda.synchronize()
+    got = y.cpu().permute(0, 3, 1, 2).double()
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max() <= _tol(ref, 1e-5)
+    r = rows.value
+    assert 0 < r <= N * Ho * Wo // 64 + 64
+    pt = part[:2 * 64 * r].view(2, 64, r).double().sum(2).cpu()
+    yd = y.double().view(-1, 64)
+    s1, s2 = yd.sum(0).cpu(), (yd * yd).sum(0).cpu()
+    assert (pt[0] - s1).abs().max() <= 1e-4 * max(1.0, float(s1.abs().max()))
+    assert (pt[1] - s2).abs().max() <= 1e-5 * float(s2.abs().max())
+    # without partials (NULL): same tensor
+    y2 = torch.empty_like(y)
+    L.check(lib.cilrs_stem_conv_fwd(L.ptr(x4), L.ptr(ohwi(w)), L.ptr(y2), None, N, H, W, None, stream()))
+    assert torch.equal(y, y2)
+
+
 @pytest.mark.parametrize("case", [(2, 22, 50, 64, 128, 1, 2, 0), (3, 11, 25, 128, 256, 1, 2, 0),
                                   (2, 22, 50, 64, 128, 3, 2, 1), (2, 7, 9, 64, 128, 1, 2, 0)])
 def test_conv_dgrad_stride2_in_place(case):
