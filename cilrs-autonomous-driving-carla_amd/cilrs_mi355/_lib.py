@@ -90,6 +90,8 @@ SIGNATURES = {
     "cilrs_loss_fwd_bwd": (i32, [vp, vp, vp, vp, i32, i32, c_float_p, f32, vp, vp, vp, vp]),
     "cilrs_net_backward": (i32, [vp, C.POINTER(Buffers), vp, vp, i32, i32, vp]),
     "cilrs_stem_conv_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp]),
+    "cilrs_stem_conv_wgrad_scratch_floats": (sz, [i32, i32, i32]),
+    "cilrs_stem_conv_wgrad": (i32, [vp, vp, vp, vp, sz, i32, i32, i32, vp]),
     "cilrs_net_backward_step": (i32, [vp, C.POINTER(Buffers), vp, vp, vp, vp]),
     "cilrs_segment_range": (i32, [i32, C.POINTER(sz), C.POINTER(sz)]),
     "cilrs_variant_segment_range": (i32, [i32, i32, C.POINTER(sz), C.POINTER(sz)]),

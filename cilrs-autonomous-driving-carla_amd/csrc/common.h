@@ -544,6 +544,11 @@ int launch_avgpool_f16(const void* x, float* out, int N, int HW, int C, int out_
 int stem_f32_rows(int N, int H, int W);
 int launch_stem_f32(const float* x4, const float* w, float* y, float* bn_partial, int N, int H, int W,
                     hipStream_t s);
+// its weight gradient: dw = OHWI [64][7][7][3], overwritten; scratch: stem_wgrad_f32_scratch_floats()
+// floats (0: geometry not served -- rows of 100 or 200 output pixels only)
+size_t stem_wgrad_f32_scratch_floats(int N, int H, int W);
+int launch_stem_wgrad_f32(const float* x4, const float* dy, float* dw, float* scratch, int N, int H,
+                          int W, hipStream_t s);
 // 16-bit stem of the serving path (stem_f16.hip): conv 7x7/s2 + folded BN + ReLU on the channel-
 // padded fp32 image -> 16-bit [N][Ho][Wo][64]; max-pool 3x3/s2/p1 on 16-bit NHWC
 int launch_fold_stem_f16(const float* w, const float* stats, void* w16, float* bias, int bf16,

@@ -2233,8 +2233,21 @@ int cilrs_net_backward(cilrs_net* net, const cilrs_buffers* bufs, const float* d
                 launch_bn_bwd_pool(ws + net->G[3], argmax, ws + g0.y, B, net->H0, net->W0, 64,
                                    P + b0.gamma, ws + g0.stats, Gp + b0.gamma, Gp + b0.beta,
                                    ws + net->bn_coef, ws + net->bn_partial, ws + net->G[1], s));
-            if (conv_wgrad(net, c0, g0, ws + net->x4, 4, ws + net->G[1], Gp + c0.w, ws, s))
+            // the stem's weight gradient runs on the main stream and uses the same slab scratch as
+            // the weight gradients of the side stream: those must have finished (between the
+            // segments of one call nothing else joins the two streams any more)
+            if (gbuf_join_all(net, s)) return 1;
+            const size_t sw = stem_wgrad_f32_scratch_floats(B, net->H, net->W);
+            if (sw > 0 && sw <= net->slabs_floats) {
+                // (the reduction over pixels on the matrix pipe, dy from global memory, the input
+                //  rows in LDS: stem_f32.hip)
+                RUN(net, "conv_wgrad.stem", 2.0 * g0.M * 64 * 147,
+                    16.0 * B * net->H * net->W + 4.0 * g0.M * 64, s,
+                    launch_stem_wgrad_f32(ws + net->x4, ws + net->G[1], Gp + c0.w, ws + net->slabs, B,
+                                          net->H, net->W, s));
+            } else if (conv_wgrad(net, c0, g0, ws + net->x4, 4, ws + net->G[1], Gp + c0.w, ws, s)) {
                 return 1;
+            }
             if (segment_done(seg)) return 1;
         }
     }
@@ -2395,6 +2408,18 @@ int cilrs_stem_conv_fwd(const float* x4, const float* w, float* y, float* bn_par
     CILRS_CHECK(rows > 0, "stem_conv_fwd: geometry %dx%dx%d not served", N, H, W);
     if (partial_rows) *partial_rows = rows;
     return launch_stem_f32(x4, w, y, bn_partial, N, H, W, reinterpret_cast<hipStream_t>(stream));
+}
+
+size_t cilrs_stem_conv_wgrad_scratch_floats(int N, int H, int W) {
+    return stem_wgrad_f32_scratch_floats(N, H, W);
+}
+int cilrs_stem_conv_wgrad(const float* x4, const float* dy, float* dw, float* scratch,
+                          size_t scratch_floats, int N, int H, int W, void* stream) {
+    CILRS_CHECK(x4 && dy && dw && scratch, "stem_conv_wgrad: NULL argument");
+    const size_t need = stem_wgrad_f32_scratch_floats(N, H, W);
+    CILRS_CHECK(need > 0, "stem_conv_wgrad: geometry %dx%dx%d not served", N, H, W);
+    CILRS_CHECK(scratch_floats >= need, "stem_conv_wgrad: scratch too small");
+    return launch_stem_wgrad_f32(x4, dy, dw, scratch, N, H, W, reinterpret_cast<hipStream_t>(stream));
 }
 
 int cilrs_scale(float* x, size_t n, const float* clip_out2, float c, void* stream) {

@@ -302,6 +302,15 @@ int cilrs_scale(float* x, size_t n, const float* clip_out2, float c, void* strea
 int cilrs_stem_conv_fwd(const float* x4, const float* w, float* y, float* bn_partial, int N, int H,
                         int W, int* partial_rows, void* stream);
 
+/* ... and its weight gradient (loss.backward() through that layer, notebook/notebook.ipynb:552):
+ * dw = OHWI [64,7,7,3] (overwritten) from x4 and dy = [N,Ho,Wo,64]; scratch of
+ * cilrs_stem_conv_wgrad_scratch_floats() floats.  Served geometries: rows of 100 or 200 output
+ * pixels (the reference's 200x88 frames and the 400x176 variant); _scratch_floats() returns 0
+ * otherwise and cilrs_conv2d_wgrad on the channel-padded image is the general path. */
+size_t cilrs_stem_conv_wgrad_scratch_floats(int N, int H, int W);
+int cilrs_stem_conv_wgrad(const float* x4, const float* dy, float* dw, float* scratch,
+                          size_t scratch_floats, int N, int H, int W, void* stream);
+
 /* loss.backward() + optimizer.step() (notebook/notebook.ipynb:552, 555) in ONE call for steps
  * without gradient clipping: cilrs_net_backward over all six segments, and the Adam update of a
  * segment's parameter range enqueued as soon as that segment's gradients are complete (on the

@@ -172,6 +172,46 @@ def test_stem_conv_fwd_with_batch_statistics(shape):
     assert torch.equal(y, y2)
 
 
+@pytest.mark.parametrize("shape", [(3, 88, 200), (2, 176, 400), (1, 88, 200), (9, 86, 199), (2, 26, 400)])
+def test_stem_conv_wgrad(shape):
+    """cilrs_stem_conv_wgrad (csrc/stem_f32.hip: the reduction over output pixels on the matrix
+    pipe, every wave the whole 64 x 147 product for its share of the pixels) against the float64
+    gradient of torch's conv2d: the reference's frame size and the variant's, one frame, an odd
+    height / width whose last tile is partial (43 rows = 10 tiles of 4 + 3; 199 pixels: a zero
+    column on the right), and fewer tiles than workgroups."""
+    L = _lib()
+    lib = L.lib()
+    N, H, W = shape
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, 3, H, W, generator=g).double().requires_grad_(False)
+    w = (torch.randn(64, 3, 7, 7, generator=g) / 147 ** 0.5).double().requires_grad_(True)
+    y = F.conv2d(x, w, None, 2, 3)
+    dy = torch.randn(y.shape, generator=g).double()
+    (ref,) = torch.autograd.grad(y, w, dy)
+    Ho, Wo = y.shape[2], y.shape[3]
+    need = lib.cilrs_stem_conv_wgrad_scratch_floats(N, H, W)
+    assert need > 0, "geometry must be served"
+    x4 = torch.zeros(N, H, W, 4)
+    x4[..., :3] = x.float().permute(0, 2, 3, 1)
+    x4[..., 3] = 5.0
+    x4 = x4.cuda()
+    dyd = dy.float().permute(0, 2, 3, 1).contiguous().cuda()
+    dw = torch.full((64, 7, 7, 3), float("nan"), device="cuda")
+    scratch = torch.full((need,), float("nan"), device="cuda")
+    L.check(lib.cilrs_stem_conv_wgrad(L.ptr(x4), L.ptr(dyd), L.ptr(dw), L.ptr(scratch), need, N, H, W,
+                                      stream()))
+    torch.cuda.synchronize()
+    got = dw.cpu().permute(0, 3, 1, 2).double()
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max() <= 2e-5 * max(1.0, float(ref.abs().max()))
+    # deterministic: a second launch gives the same bits
+    dw2 = torch.empty_like(dw)
+    L.check(lib.cilrs_stem_conv_wgrad(L.ptr(x4), L.ptr(dyd), L.ptr(dw2), L.ptr(scratch), need, N, H, W,
+                                      stream()))
+    assert torch.equal(dw, dw2)
+    assert lib.cilrs_stem_conv_wgrad_scratch_floats(2, 30, 70) == 0      # (served by cilrs_conv2d_wgrad)
+
+
 @pytest.mark.parametrize("case", [(2, 22, 50, 64, 128, 1, 2, 0), (3, 11, 25, 128, 256, 1, 2, 0),
                                   (2, 22, 50, 64, 128, 3, 2, 1), (2, 7, 9, 64, 128, 1, 2, 0)])
 def test_conv_dgrad_stride2_in_place(case):

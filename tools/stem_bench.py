@@ -49,3 +49,20 @@ for (N, H, W) in ((128, 88, 200), (64, 176, 400)):
     print(f"stem fwd N={N} {H}x{W}: stem_f32 {tn:7.1f} us ({fl / tn / 1e6:6.1f} TF, {rows.value} tiles)   "
           f"implicit GEMM (Cin 4) {to:7.1f} us ({fl / to / 1e6:6.1f} TF)   max |diff| "
           f"{(y - y2).abs().max().item():.2e}", flush=True)
+    # weight gradient
+    dy = torch.randn(N, Ho, Wo, 64, device="cuda")
+    need = lib.cilrs_stem_conv_wgrad_scratch_floats(N, H, W)
+    sc2 = torch.empty(max(need, 64 << 20), device="cuda")
+    dw = torch.empty(64, 7, 7, 3, device="cuda")
+    dw4 = torch.empty(64, 7, 7, 3, device="cuda")
+
+    def wnew():
+        L.check(lib.cilrs_stem_conv_wgrad(L.ptr(x4), L.ptr(dy), L.ptr(dw), L.ptr(sc2), sc2.numel(), N, H, W, st))
+
+    def wold():
+        L.check(lib.cilrs_conv2d_wgrad(L.ptr(x4), L.ptr(dy), L.ptr(dw4), L.ptr(sc2), N, H, W, 4, 64, 7, 7,
+                                       2, 3, 3, st))
+    tn, to = timed(wnew), timed(wold)
+    print(f"stem wgrad N={N} {H}x{W}: stem_f32 {tn:7.1f} us ({fl / tn / 1e6:6.1f} TF)   implicit GEMM (Cin 4) "
+          f"{to:7.1f} us ({fl / to / 1e6:6.1f} TF)   max |diff| {(dw - dw4).abs().max().item():.2e} "
+          f"(max |dw| {dw4.abs().max().item():.1f})", flush=True)
