@@ -550,9 +550,12 @@ int conv_dgrad(cilrs_net* net, const ConvT& c, const ConvG& g, const float* dy, 
         // gradients of the side stream already fill the CUs a last round leaves idle, and a
         // second launch per data gradient costs more in boundaries than it gains (step 11.09 vs
         // 10.99 ms with tails on both sides, profiles/r03_wino_tail.log)
+        // Re-measured in round 4 with both kinds of block in ONE launch (CILRS_WINO_DGRAD_TAIL=1 of
+        // an experiments build): the data-gradient family 3.29 -> 3.04 ms serialised, the
+        // overlapped step 9.32 -> 9.50 ms.
         // (decided by the plan's configuration, not by whether this step is being profiled: the
         //  profiled steps of bench.py must run the kernels the timed steps ran)
-        wa.no_tail = overlap_configured(net) ? 1 : 0;
+        wa.no_tail = (overlap_configured(net) && !experiment_env("CILRS_WINO_DGRAD_TAIL", 0)) ? 1 : 0;
         wa.slabs = ws + net->ksplit; wa.slab_floats = net->ksplit_floats;
         wa.scratch_partial = ws + net->bn_partial;
         if (bwd_nblk) *bwd_nblk = 0;
