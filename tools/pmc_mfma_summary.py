@@ -14,8 +14,14 @@ for r in csv.DictReader(open(f)):
     n = r["Kernel_Name"]
     if "conv_wino_q_kernel" in n:
         fam = "conv_wino_q_kernel"
+    elif "conv_wino_kernel<true>" in n:
+        fam = "conv_wino_kernel_dgrad_epilogue"          # (the epilogue-prefetch variant, also counted below)
     elif "conv_wino_kernel" in n:
         fam = "conv_wino_kernel"
+    elif "stem_wgrad_f32_kernel" in n:
+        fam = "stem_wgrad_f32_kernel"
+    elif "stem_f32_kernel" in n:
+        fam = "stem_f32_kernel"
     elif "wino_wgrad_kernel" in n:
         fam = "wino_wgrad_kernel"
     elif "conv_igemm_kernel<128" in n:
@@ -30,6 +36,8 @@ for r in csv.DictReader(open(f)):
         continue
     key = (fam, r["Dispatch_Id"])
     agg.setdefault(key, {})[r["Counter_Name"]] = float(r["Counter_Value"])
+    if fam == "conv_wino_kernel_dgrad_epilogue":
+        agg.setdefault(("conv_wino_kernel", r["Dispatch_Id"]), {})[r["Counter_Name"]] = float(r["Counter_Value"])
 res = {}
 for (fam, _), c in agg.items():
     if "GRBM_GUI_ACTIVE" not in c or c["GRBM_GUI_ACTIVE"] < 8 * 20000:     # skip the heads' tiny launches

@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/stall
 rm -rf $OUT; mkdir -p $OUT
 export CILRS_OVERLAP=0
-CMD="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-infer --profile-steps 0"
+CMD="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-infer --no-loader --profile-steps 0"
 rocprofv3 --kernel-trace --pmc SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/a -- $CMD > $OUT/a.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INST_LEVEL_LDS SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_LDS_CMD_FIFO_FULL SQ_LDS_DATA_FIFO_FULL SQ_ACTIVE_INST_MISC SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d $OUT/b -- $CMD > $OUT/b.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_VALU_MFMA_COEXEC_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/c -- $CMD > $OUT/c.log 2>&1

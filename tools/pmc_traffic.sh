@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/traffic
 mkdir -p $OUT
-CMD="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-infer --profile-steps 0"
+CMD="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-infer --no-loader --profile-steps 0"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $CMD > $OUT/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $CMD > $OUT/write.log 2>&1
 python3 $R/tools/pmc_traffic_summary.py $OUT ${1:-unknown} > $OUT/summary.log 2>&1

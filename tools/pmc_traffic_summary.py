@@ -23,7 +23,9 @@ def load(sub, counter):
         # are also listed on their own
         fams = ["igemm", "igemm_only"] if "conv_igemm_kernel" in n else \
             ["igemm", "wino_only"] if "conv_wino" in n else \
+            ["igemm", "stem_only"] if "stem_f32_kernel" in n else \
             ["wgrad", "wgrad_direct_only"] if "conv_wgrad_kernel" in n else \
+            ["wgrad", "wgrad_stem_only"] if "stem_wgrad_f32_kernel" in n else \
             ["wgrad", "wgrad_wino_only"] if "wino_wgrad_kernel" in n else []
         # a Winograd convolution may be two kernel launches (64-tile blocks + the 16-tile tail,
         # conv_wino_q_kernel): the tail's bytes count, the tail is not a launch of its own -- so
@@ -39,7 +41,7 @@ def load(sub, counter):
 fe, wr = load("fetch", "FETCH_SIZE"), load("write", "WRITE_SIZE")
 res = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on `bench.py --steps 3 --warmup 1` "
                  "(tools/pmc_traffic.sh); FETCH_SIZE x2 per the gfx950 correction; KiB -> bytes; "
-                 "igemm = forward + data-gradient family (conv_igemm_kernel + conv_wino_kernel)",
+                 "igemm = forward + data-gradient family (conv_igemm_kernel + conv_wino_kernel + stem_f32_kernel)",
        "commit": sys.argv[2] if len(sys.argv) > 2 else "unknown"}
 for fam in fe:
     n = fe[fam][0]
