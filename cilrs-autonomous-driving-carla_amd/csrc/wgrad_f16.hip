@@ -191,24 +191,36 @@ __global__ __launch_bounds__(256, 2) void wgrad_f16_kernel(const WgradF16Args a,
         }
 }
 
-// sum of the slabs in slab order (float4 per thread)
+// sum of the slabs in a fixed order.  Small tensors are cut into many slabs (a 64 x 64 1x1
+// convolution: 1,024 float4 outputs, up to 512 slabs): one thread per output walking all of them
+// was 40 us of dependent loads on four workgroups.  32 outputs x 8 slab groups per block: a thread
+// adds the slabs k = g, g + 8, ... of its output, thread group 0 the eight partial sums.
 __global__ __launch_bounds__(256) void wgrad_f16_reduce_kernel(const float* __restrict__ slabs,
                                                                float* __restrict__ dw,
                                                                const int splits, const size_t n4) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
-         i += (size_t)gridDim.x * blockDim.x) {
-        f32x4 acc[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        int sidx = 0;
-        for (; sidx + 3 < splits; sidx += 4) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                acc[u] += *reinterpret_cast<const f32x4*>(slabs + ((size_t)(sidx + u) * n4 + i) * 4);
+    __shared__ f32x4 part[8][32];
+    const int o = threadIdx.x & 31, g = threadIdx.x >> 5;
+    for (size_t base = (size_t)blockIdx.x * 32; base < n4; base += (size_t)gridDim.x * 32) {   // (block-uniform)
+        const size_t i = base + o;
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        if (i < n4) {
+            int sidx = g;
+            for (; sidx + 8 < splits; sidx += 16) {
+                acc[0] += *reinterpret_cast<const f32x4*>(slabs + ((size_t)sidx * n4 + i) * 4);
+                acc[1] += *reinterpret_cast<const f32x4*>(slabs + ((size_t)(sidx + 8) * n4 + i) * 4);
+            }
+            if (sidx < splits)
+                acc[0] += *reinterpret_cast<const f32x4*>(slabs + ((size_t)sidx * n4 + i) * 4);
         }
-        for (; sidx < splits; ++sidx)
-            acc[0] += *reinterpret_cast<const f32x4*>(slabs + ((size_t)sidx * n4 + i) * 4);
-        *reinterpret_cast<f32x4*>(dw + i * 4) = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        part[g][o] = acc[0] + acc[1];
+        __syncthreads();
+        if (g == 0 && i < n4) {
+            f32x4 r = part[0][o];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) r += part[q][o];
+            *reinterpret_cast<f32x4*>(dw + i * 4) = r;
+        }
+        __syncthreads();
     }
 }
 
@@ -278,7 +290,7 @@ int launch_wgrad_f16(const WgradF16Args& a, hipStream_t s) {
     if (rc) return rc;
     if (p.splits > 1) {
         const size_t n4 = (size_t)a.Cout * a.K * a.K * a.Cin / 4;
-        const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+        const int blocks = (int)((n4 + 31) / 32 < 4096 ? (n4 + 31) / 32 : 4096);
         wgrad_f16_reduce_kernel<<<blocks, 256, 0, s>>>(a.slabs, a.dw, p.splits, n4);
         CILRS_LAUNCH_CHECK();
     }
