@@ -201,8 +201,10 @@ def main():
     ap.add_argument("--no-infer", action="store_true")
     ap.add_argument("--no-loader", action="store_true",
                     help="skip the input-pipeline leg (JPEG decode pool -> augmentation -> train step)")
-    ap.add_argument("--two-call-step", action="store_true",
-                    help="backward, then one Adam launch (A/B of cilrs_net_backward_step's per-segment Adam)")
+    ap.add_argument("--fused-step", action="store_true",
+                    help="cilrs_net_backward_step (per-segment Adam on the weight-gradient stream) instead of "
+                         "backward + one Adam launch: same numbers, 0.3 %% slower (A/B)")
+    ap.add_argument("--two-call-step", action="store_true", help="(the default since round 4; kept for scripts)")
     ap.add_argument("--force-dp", action="store_true",
                     help="use the bucketed all-reduce path even with one rank (rehearsal)")
     ap.add_argument("--rehearse", action="store_true",
@@ -254,8 +256,7 @@ def main():
     cfg = CONFIG_A if args.config == "A" else TrainConfig(**{**CONFIG_B.__dict__})
     model = CILRS(4, dropout=cfg.dropout).to(dev)
     trainer = Trainer(model, cfg, process_group=pg)
-    if args.two_call_step:
-        trainer.fuse_optimizer = False
+    trainer.fuse_optimizer = bool(args.fused_step)
     if pg is not None:
         broadcast_parameters(trainer.eng, pg)
     batch, u8 = synthetic_batch(args.batch, 1 + rank, dev)

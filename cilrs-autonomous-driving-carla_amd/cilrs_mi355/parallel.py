@@ -51,13 +51,25 @@ class BucketedAllReduce:
             w.wait()
         self._pending.clear()
 
-    def backward_and_reduce(self, eng, plan, dcontrols, dpred_speed):
+    def backward_and_reduce(self, eng, plan, dcontrols, dpred_speed, after_bucket=None):
+        """Segment-wise backward, one asynchronous all-reduce per finished bucket.  after_bucket
+        (i, begin, end), if given, is called for every bucket in issue order once the compute
+        stream has been made to wait for that bucket's collective -- the Trainer updates the
+        bucket's parameter range there, so the Adam launches of the early (large) buckets run
+        while the last (small) bucket's all-reduce, which nothing else can hide, is in flight."""
         seg = 0
         for i, (last_seg, _, _) in enumerate(self.buckets):
             eng.run_backward(plan, dcontrols, dpred_speed, seg, last_seg + 1)
             seg = last_seg + 1
             self.reduce_bucket(i)
-        self.wait_all()
+        if after_bucket is None:
+            self.wait_all()
+            return
+        for i, w in enumerate(self._pending):
+            w.wait()
+            _, b, e = self.buckets[i]
+            after_bucket(i, b, e)
+        self._pending.clear()
 
 
 def broadcast_parameters(eng, process_group=None, src=0):

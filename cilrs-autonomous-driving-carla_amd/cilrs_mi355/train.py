@@ -79,9 +79,17 @@ class Trainer:
         self._kind = 1 if cfg.loss == "l1" else 0
         self._seed_calls = 0
         self.arena_grad_scale = 1.0
-        # single-GPU steps without clipping take cilrs_net_backward_step (False: backward, then
-        # one Adam launch over the arena -- the same numbers, element by element)
-        self.fuse_optimizer = True
+        # True: single-GPU steps without clipping take cilrs_net_backward_step (a segment's Adam
+        # update enqueued behind its gradients, on the weight-gradient stream) instead of backward +
+        # one Adam launch over the arena -- the same numbers, element by element.  Off by default:
+        # the overlapped step is bound by the kernels' resource time, not by its critical path,
+        # and the six extra stream forks cost more than the overlap gains (9.24 vs 9.215 ms,
+        # tools/dp_overhead.sh).
+        self.fuse_optimizer = False
+        # data parallel without clipping: Adam per all-reduce bucket as soon as the bucket's
+        # averaged gradient is there (the last, small bucket's collective runs under the first two
+        # buckets' updates)
+        self.bucket_optimizer = True
         self.reducer = None
         self.rank = 0
         if process_group is not None:
@@ -162,10 +170,29 @@ class Trainer:
         elif self.reducer is None:
             eng.run_backward(pl, dc, dp)
             self.optimizer_step(1.0)
+        elif self.cfg.grad_clip <= 0 and self.bucket_optimizer:
+            # data parallel without clipping: Adam per all-reduce bucket, as soon as the bucket's
+            # averaged gradient is there (the last bucket's collective runs under the first two
+            # buckets' updates); same numbers as one launch over the arena
+            self.step_count += 1
+            eng.weights_epoch += 1
+            scale = 1.0 / self.reducer.world_size
+            self.arena_grad_scale = scale
+            self.reducer.backward_and_reduce(
+                eng, pl, dc, dp, after_bucket=lambda _i, b, e: self._adam_range(b, e, scale))
         else:
             self.reducer.backward_and_reduce(eng, pl, dc, dp)
             self.optimizer_step(1.0 / self.reducer.world_size)
         return self.loss_buf
+
+    def _adam_range(self, begin, end, grad_scale):
+        """cilrs_adam_step over the arena range [begin, end) (step_count already advanced)."""
+        eng, cfg = self.eng, self.cfg
+        L.check(L.lib().cilrs_adam_step(
+            L.ptr(eng.params[begin:end]), L.ptr(eng.grads[begin:end]),
+            L.ptr(self.exp_avg[begin:end]), L.ptr(self.exp_avg_sq[begin:end]), end - begin, self.lr,
+            cfg.betas[0], cfg.betas[1], cfg.eps, cfg.weight_decay, self.step_count, None,
+            float(grad_scale), self._stream()))
 
     def next_dropout_seed(self):
         """Seed of the next train step's dropout masks: torch's seed, the step count and the

@@ -418,6 +418,17 @@ int zero_counters_once(cilrs_net* net, void* workspace, hipStream_t s) {
     return 0;
 }
 
+// Events that only order one stream of this device behind another (hipStreamWaitEvent; the host
+// never inspects them).  hipEventDisableSystemFence: by default a HIP event performs a SYSTEM-scope
+// release when it is recorded -- a cache write-back / invalidate so that the HOST may synchronise
+// with it -- ~70 times per backward pass here (one fork and one join per weight gradient).  Without
+// it the step is 0.13 ms shorter (9.37 -> 9.25 ms, tools/ab_env.sh CILRS_EVENT_NOFENCE 0 1); the
+// device-side ordering of hipStreamWaitEvent is not affected (the kernels' own agent-scope
+// releases make their results visible to the other stream).
+unsigned stream_event_flags() {
+    static const int nofence = experiment_env("CILRS_EVENT_NOFENCE", 1);
+    return hipEventDisableTiming | (nofence ? hipEventDisableSystemFence : 0u);
+}
 int ensure_streams(cilrs_net* net) {
     if (net->streams_ready) return 0;
     int prio_least = 0, prio_greatest = 0;
@@ -441,8 +452,8 @@ int ensure_streams(cilrs_net* net) {
     else
         CILRS_HIP(hipStreamCreateWithFlags(&net->side[0], hipStreamNonBlocking));
     for (int i = 0; i < kNumG; ++i)
-        CILRS_HIP(hipEventCreateWithFlags(&net->gbuf_ev[i], hipEventDisableTiming));
-    CILRS_HIP(hipEventCreateWithFlags(&net->fork_ev, hipEventDisableTiming));
+        CILRS_HIP(hipEventCreateWithFlags(&net->gbuf_ev[i], stream_event_flags()));
+    CILRS_HIP(hipEventCreateWithFlags(&net->fork_ev, stream_event_flags()));
     net->streams_ready = true;
     return 0;
 }
