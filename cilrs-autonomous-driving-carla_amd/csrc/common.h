@@ -608,5 +608,7 @@ int launch_adam(float* p, const float* g, float* m, float* v, size_t n, double l
                 double beta2, double eps, double wd, long long step, const float* clip_out,
                 float gscale, hipStream_t s);
 int launch_scale(float* g, size_t n, const float* coef_ptr, float c, hipStream_t s);
+int launch_keep_head_inputs(const float* speed, const long long* cmd, float* speed_dst,
+                            long long* cmd_dst, int B, hipStream_t s);
 
 }  // namespace cilrs

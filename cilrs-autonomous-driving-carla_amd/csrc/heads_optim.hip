@@ -726,6 +726,26 @@ int launch_eval_accumulate(const float* pc, const float* tc, const float* ps, co
     return 0;
 }
 
+// the backward pass needs the inputs of the heads: one launch instead of two device-to-device
+// hipMemcpyAsync calls (blit kernels with their own fences in the middle of the step)
+namespace {
+__global__ void keep_head_inputs_kernel(const float* __restrict__ speed, const long long* __restrict__ cmd,
+                                        float* __restrict__ speed_dst, long long* __restrict__ cmd_dst,
+                                        const int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) {
+        speed_dst[i] = speed[i];
+        cmd_dst[i] = cmd[i];
+    }
+}
+}  // namespace
+int launch_keep_head_inputs(const float* speed, const long long* cmd, float* speed_dst,
+                            long long* cmd_dst, int B, hipStream_t s) {
+    keep_head_inputs_kernel<<<cdiv(B, 256), 256, 0, s>>>(speed, cmd, speed_dst, cmd_dst, B);
+    CILRS_LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_branch_gather(const float* all_out, const long long* cmd, float* controls, int B,
                          int nbranch, int* status, hipStream_t s) {
     branch_gather_kernel<<<cdiv(B * 3, 256), 256, 0, s>>>(all_out, cmd, controls, B, nbranch,

@@ -1472,10 +1472,9 @@ static int forward_from_x4(cilrs_net* net, const cilrs_buffers* bufs, const floa
             launch_avgpool_fwd(cur, ws + net->combined, B, net->featHW, feat, comb, s));
 
     if (train) {   // backward needs the inputs of the heads
-        CILRS_HIP(hipMemcpyAsync(ws + net->speed_in, speed, (size_t)B * sizeof(float),
-                                 hipMemcpyDeviceToDevice, s));
-        CILRS_HIP(hipMemcpyAsync(reinterpret_cast<char*>(bufs->workspace) + net->cmd_b, command,
-                                 (size_t)B * sizeof(int64_t), hipMemcpyDeviceToDevice, s));
+        if (launch_keep_head_inputs(speed, reinterpret_cast<const long long*>(command), ws + net->speed_in,
+                                    reinterpret_cast<long long*>(reinterpret_cast<char*>(bufs->workspace) +
+                                                                 net->cmd_b), B, s)) return 1;
     }
     const float pdrop = train ? dropout_p : 0.f;
     // Every layer of every chain that can run at the same time is ONE grouped launch
