@@ -240,8 +240,12 @@ struct Prof {
             pool.pop_back();
             return e;
         }
+        // timing events: no system-scope release at the record (hipEventDisableSystemFence is
+        // meant for exactly this: the cache write-back / invalidate between two kernels is not
+        // part of either kernel, and the unprofiled step does not have it)
         hipEvent_t e;
-        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        const unsigned flags = experiment_env("CILRS_PROF_NOFENCE", 1) ? hipEventDisableSystemFence : 0u;
+        if (hipEventCreateWithFlags(&e, flags) != hipSuccess) return nullptr;
         return e;
     }
     int collect() {
