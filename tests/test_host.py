@@ -175,6 +175,17 @@ def _dp_worker(rank, world, port, q):
     others = [torch.randn(n, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]
     want = sum(others)
     ok = bool(torch.allclose(flat, want, atol=1e-5)) and not torch.equal(flat, mine)
+    # the per-bucket hook (the Trainer updates a bucket's parameter range there): called once per
+    # bucket, in issue order, with the bucket's range, and the bucket is REDUCED when it is called
+    flat.copy_(mine)
+    seen = []
+
+    def after(i, b, e):
+        seen.append((i, b, e, bool(torch.allclose(flat[b:e], want[b:e], atol=1e-5))))
+    red.backward_and_reduce(eng, None, None, None, after_bucket=after)
+    plan = bucket_plan(segs)
+    ok = ok and [(i, b, e) for i, b, e, _ in seen] == [(i, b, e) for i, (_, b, e) in enumerate(plan)] \
+        and all(x[3] for x in seen) and not red._pending
     q.put((rank, ok, red.world_size))
     dist.destroy_process_group()
 
