@@ -260,8 +260,10 @@ bool stem_f32_plan(int N, int H, int W, int Ho, int Wo, StemPlan* p) {
 template <int TM, int PITCH, bool DB>
 int launch_stem_f32_t(const StemF32Args& a, const StemPlan& p, hipStream_t s) {
     if (once_per_device(reinterpret_cast<const void*>(&stem_f32_kernel<TM, PITCH, DB>))) {
+        // (the row count, hence the LDS size, of one instantiation varies with the image width: set
+        //  the limit to the CU's 160 KB once, not to the first caller's size)
         CILRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_f32_kernel<TM, PITCH, DB>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     const int resident = device_cus() * (DB ? 1 : 2);
     stem_f32_kernel<TM, PITCH, DB><<<p.ntiles < resident ? p.ntiles : resident, 512, p.lds, s>>>(a);

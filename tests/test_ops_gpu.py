@@ -130,14 +130,15 @@ def test_conv_dgrad(case, cfg, splitk, with_addend):
     assert (got - want).abs().max() <= _tol(want)
 
 
-@pytest.mark.parametrize("shape", [(5, 88, 200), (3, 176, 400), (2, 30, 70), (1, 88, 200), (3, 9, 253),
-                                   (2, 61, 445)])
+@pytest.mark.parametrize("shape", [(5, 88, 200), (2, 40, 120), (3, 176, 400), (2, 30, 70), (1, 88, 200),
+                                   (3, 9, 253), (2, 61, 445)])
 def test_stem_conv_fwd_with_batch_statistics(shape):
     """cilrs_stem_conv_fwd (csrc/stem_f32.hip: conv 7x7 / stride 2 / pad 3 of the training step, the
     weights in registers, k = 7 x 22) against torch's conv2d on the CPU, and its per-tile column
     partials against the sums of its own output: the reference's frame size, the ResNet-50 variant's,
-    odd sizes with partial last tiles, rows that end inside / at the edge of a 64-pixel DMA segment
-    and the widest rows either row pitch serves."""
+    odd sizes with partial last tiles (one right after the reference size that needs MORE LDS from
+    the same kernel instantiation), rows that end inside / at the edge of a 64-pixel DMA segment and
+    the widest rows either row pitch serves."""
     L = _lib()
     lib = L.lib()
     N, H, W = shape
