@@ -316,7 +316,8 @@ struct cilrs_net {
     bool overlap = true;
     bool streams_ready = false;
     hipStream_t side[1];                   // weight-gradient stream
-    hipEvent_t fork_ev, gbuf_ev[kNumG];
+    hipEvent_t fork_ev, gbuf_ev[kNumG], wprep_ev;
+    bool wprep_pending = false;            // this step's weight images are being built on the side stream
     bool gbuf_pending[kNumG] = {};
     int dy_pos = 0;
     int bwd_nblk_next = 0;                 // fused BN-backward partials waiting for their BN
@@ -458,6 +459,7 @@ int ensure_streams(cilrs_net* net) {
     for (int i = 0; i < kNumG; ++i)
         CILRS_HIP(hipEventCreateWithFlags(&net->gbuf_ev[i], stream_event_flags()));
     CILRS_HIP(hipEventCreateWithFlags(&net->fork_ev, stream_event_flags()));
+    CILRS_HIP(hipEventCreateWithFlags(&net->wprep_ev, stream_event_flags()));
     net->streams_ready = true;
     return 0;
 }
@@ -1098,6 +1100,7 @@ void cilrs_net_destroy(cilrs_net* net) {
         (void)hipStreamDestroy(net->side[0]);
         for (int i = 0; i < kNumG; ++i) (void)hipEventDestroy(net->gbuf_ev[i]);
         (void)hipEventDestroy(net->fork_ev);
+        (void)hipEventDestroy(net->wprep_ev);
     }
     if (net && net->graph_exec) (void)hipGraphExecDestroy(net->graph_exec);
     delete net;
@@ -1195,6 +1198,32 @@ static int forward_from_x4(cilrs_net* net, const cilrs_buffers* bufs, const floa
     if (train) { net->prep_key = 0; net->fold_key = 0; }     // weights / BN buffers are about to change
     const float* cur;
     if (train) {
+        // this step's weight images -- the Winograd-transformed filters (forward + data-gradient
+        // forms), in the bf16 mode the 16-bit arena and the transposed, tap-flipped copies the data
+        // gradients read -- depend on the parameters only: they are built on the side stream while
+        // the stem and the max-pool run (memory-bound launches beside a matrix-pipe-bound one); the
+        // first residual block waits for them
+        {
+            hipStream_t ts = s;
+            const bool fork = use_overlap(net) && (net->wino_table.n || bf16t);
+            if (fork) {
+                if (gbuf_side_begin(net, s)) return 1;
+                ts = net->side[0];
+            }
+            if (net->wino_table.n)
+                RUN(net, "transform", 0.0, 4.0 * 4.6 * (double)net->wino_table.blk_begin[net->wino_table.n] * 256, ts,
+                    launch_wino_weights_all(net->wino_table, P, ws + net->wino_base, ts));
+            if (bf16t) {
+                RUN(net, "transform", 0.0, 6.0 * A.arena_floats, ts,
+                    launch_f32_to_f16(P, h16(ws, net->w16_all), A.arena_floats, 1, ts));
+                RUN(net, "transform", 0.0, 0.0, ts,
+                    launch_transpose_flip_f16_all(net->tr_table, P, h16(ws, net->wT16), 1, ts));
+            }
+            if (fork) {
+                CILRS_HIP(hipEventRecord(net->wprep_ev, ts));
+                net->wprep_pending = true;
+            }
+        }
         int nb = 0;                             // batch statistics fused into the conv epilogue
         if (const int srows = stem_f32_rows(B, net->H, net->W)) {
             // (weights in registers, k = 7 x 22 instead of 13 x 16: stem_f32.hip)
@@ -1225,16 +1254,10 @@ static int forward_from_x4(cilrs_net* net, const cilrs_buffers* bufs, const floa
             launch_bn_relu_maxpool_fwd(ws + net->cg[0].y, ws + net->cg[0].stats, ws + net->pool,
                                        argmax, B, net->H0, net->W0, 64, s,
                                        bf16t ? (void*)h16(ws, net->pool16) : nullptr));
-        if (net->wino_table.n)       // this step's transformed filters (forward + data-gradient forms)
-            RUN(net, "transform", 0.0, 4.0 * 4.6 * (double)net->wino_table.blk_begin[net->wino_table.n] * 256, s,
-                launch_wino_weights_all(net->wino_table, P, ws + net->wino_base, s));
-        if (bf16t) {
-            // this step's 16-bit weights: the whole arena (same offsets as fp32) and the
-            // transposed, tap-flipped copies the data gradients read
-            RUN(net, "transform", 0.0, 6.0 * A.arena_floats, s,
-                launch_f32_to_f16(P, h16(ws, net->w16_all), A.arena_floats, 1, s));
-            RUN(net, "transform", 0.0, 0.0, s,
-                launch_transpose_flip_f16_all(net->tr_table, P, h16(ws, net->wT16), 1, s));
+        // (this step's weight images were requested before the stem, on the side stream)
+        if (net->wprep_pending) {
+            CILRS_HIP(hipStreamWaitEvent(s, net->wprep_ev, 0));
+            net->wprep_pending = false;
         }
         // ---- residual blocks: BasicBlock conv-BN-ReLU-conv-BN-(+id)-ReLU, Bottleneck with a third
         //      conv-BN pair; the identity (or downsample branch) joins at the last BatchNorm ----
