@@ -308,7 +308,7 @@ struct cilrs_net {
     const void* cnt_zeroed_for = nullptr;  // workspace whose counters have been zeroed
     size_t G[kNumG];                       // gradient buffers: [1..3] fixed roles, the rest = dy ring
     size_t gmax;
-    size_t bn_partial, bn_coef, slabs, slabs_floats, ksplit, ksplit_floats, status_b;
+    size_t bn_partial, bn_partial2, bn_coef, slabs, slabs_floats, ksplit, ksplit_floats, status_b;
     size_t ws_bytes;
     float* ws_base = nullptr;             // workspace of the current call (set by every entry)
     // side streams: independent kernels (weight-gradient vs data-gradient GEMMs, the five head
@@ -316,7 +316,9 @@ struct cilrs_net {
     bool overlap = true;
     bool streams_ready = false;
     hipStream_t side[1];                   // weight-gradient stream
-    hipEvent_t fork_ev, gbuf_ev[kNumG], wprep_ev;
+    hipEvent_t fork_ev, gbuf_ev[kNumG], wprep_ev, branch_ev;
+    int side_branch = 0;                   // conv_fwd / conv_fwd16 are building a down-sample branch on the side stream:
+                                           // its own column-partial scratch, no split-K scratch
     bool wprep_pending = false;            // this step's weight images are being built on the side stream
     bool gbuf_pending[kNumG] = {};
     int dy_pos = 0;
@@ -460,6 +462,7 @@ int ensure_streams(cilrs_net* net) {
         CILRS_HIP(hipEventCreateWithFlags(&net->gbuf_ev[i], stream_event_flags()));
     CILRS_HIP(hipEventCreateWithFlags(&net->fork_ev, stream_event_flags()));
     CILRS_HIP(hipEventCreateWithFlags(&net->wprep_ev, stream_event_flags()));
+    CILRS_HIP(hipEventCreateWithFlags(&net->branch_ev, stream_event_flags()));
     net->streams_ready = true;
     return 0;
 }
@@ -539,10 +542,14 @@ int conv_fwd(cilrs_net* net, const ConvT& c, const ConvG& g, const float* x, int
     a.KH = a.KW = c.k; a.stride = c.stride; a.pad = c.pad;
     a.x_ld = x_cin; a.y_ld = c.cout; a.w_mode = 0; a.w_cin = x_cin;
     a.scratch = ws + net->ksplit; a.scratch_floats = net->ksplit_floats;
+    if (net->side_branch) { a.scratch = nullptr; a.scratch_floats = 0; }     // (no split-K beside the main stream's)
     a.tile_counters = reinterpret_cast<int*>(ws + net->tile_cnt);
     a.tile_counters_cap = kTileCounters;
     a.force_cfg = -1;
-    if (bn_nblk) { a.bn_partial = ws + net->bn_partial; a.bn_nblk = bn_nblk; *bn_nblk = 0; }
+    if (bn_nblk) {
+        a.bn_partial = ws + (net->side_branch ? net->bn_partial2 : net->bn_partial);
+        a.bn_nblk = bn_nblk; *bn_nblk = 0;
+    }
     const double flops = 2.0 * g.M * c.cout * c.k * c.k * c.cin;
     const double bytes = 4.0 * ((double)net->B * g.H * g.W * c.cin + (double)g.M * c.cout +
                                 (double)c.cout * c.k * c.k * c.cin);
@@ -666,7 +673,7 @@ int conv_fwd16(cilrs_net* net, const ConvT& c, const ConvG& g, int ci, const cil
     ConvF16Args a;
     memset(&a, 0, sizeof(a));
     a.x = x16; a.w = h16(ws, net->w16_all) + c.w; a.y16 = y16_of(net, ws, ci);
-    a.bn_partial = ws + net->bn_partial;
+    a.bn_partial = ws + (net->side_branch ? net->bn_partial2 : net->bn_partial);
     a.N = net->B; a.H = g.H; a.W = g.W; a.Cin = c.cin; a.Ho = g.Ho; a.Wo = g.Wo; a.Cout = c.cout;
     a.K = c.k; a.stride = c.stride; a.pad = c.pad; a.bf16 = 1;
     *bn_nblk = conv_f16_train_mtiles(a);
@@ -978,6 +985,7 @@ int cilrs_net_create_ex(int variant, int batch, int height, int width, unsigned 
                     need = bn_partial_floats(A.convs[ci].cout);
             }
         n->bn_partial = bump.take(need);
+        n->bn_partial2 = bump.take(need);      // (the down-sample branch of a block, built beside conv1)
     }
     n->bn_coef = bump.take(3 * 2048);
     n->slabs_floats = slabs_max;
@@ -1101,6 +1109,7 @@ void cilrs_net_destroy(cilrs_net* net) {
         for (int i = 0; i < kNumG; ++i) (void)hipEventDestroy(net->gbuf_ev[i]);
         (void)hipEventDestroy(net->fork_ev);
         (void)hipEventDestroy(net->wprep_ev);
+        (void)hipEventDestroy(net->branch_ev);
     }
     if (net && net->graph_exec) (void)hipGraphExecDestroy(net->graph_exec);
     delete net;
@@ -1159,29 +1168,32 @@ static int forward_from_x4(cilrs_net* net, const cilrs_buffers* bufs, const floa
     const bool bf16t = train && net->bf16_train;      // trunk convolutions on the bf16 matrix pipe
 
     // (residual: fp32 tensor, or the bf16 identity in the bf16 training mode)
-    auto bn = [&](int ci, const void* residual_v, int relu, int pre_nblk) -> int {
+    auto bn = [&](int ci, const void* residual_v, int relu, int pre_nblk, hipStream_t st = nullptr,
+                  bool side_branch = false) -> int {
+        if (st == nullptr) st = s;
+        float* const partial = ws + (side_branch ? net->bn_partial2 : net->bn_partial);
         const float* residual = reinterpret_cast<const float*>(residual_v);
         const ConvT& c = A.convs[ci];
         const ConvG& g = net->cg[ci];
         const BnT& b = A.bns[c.bn];
         const double bytes = 4.0 * g.M * c.cout * (residual ? 4.0 : 3.0);
         if (bf16t) {         // 16-bit tensors: residual is the bf16 identity
-            RUN(net, std::string("bn_fwd.") + kGroupName[c.group], 0.0, bytes / 2.0, s,
+            RUN(net, std::string("bn_fwd.") + kGroupName[c.group], 0.0, bytes / 2.0, st,
                 launch_bn16_train_fwd(y16_of(net, ws, ci), g.M, c.cout, P + b.gamma, P + b.beta,
                                       R + b.rm, R + b.rv,
                                       reinterpret_cast<long long*>(bufs->bn_nbt) + c.bn, mom, eps,
-                                      residual, relu, ws + g.stats, ws + net->bn_partial,
-                                      h16(ws, net->z16[ci]), pre_nblk, s));
+                                      residual, relu, ws + g.stats, partial,
+                                      h16(ws, net->z16[ci]), pre_nblk, st));
         } else if (train) {
-            RUN(net, std::string("bn_fwd.") + kGroupName[c.group], 0.0, bytes, s,
+            RUN(net, std::string("bn_fwd.") + kGroupName[c.group], 0.0, bytes, st,
                 launch_bn_train_fwd(ws + g.y, g.M, c.cout, P + b.gamma, P + b.beta, R + b.rm,
                                     R + b.rv, reinterpret_cast<long long*>(bufs->bn_nbt) + c.bn,
-                                    mom, eps, residual, relu, ws + g.stats, ws + net->bn_partial,
-                                    ws + g.z, pre_nblk, s, nullptr, bn_sync(net, ws, 0)));
+                                    mom, eps, residual, relu, ws + g.stats, partial,
+                                    ws + g.z, pre_nblk, st, nullptr, side_branch ? nullptr : bn_sync(net, ws, 0)));
         } else {
-            RUN(net, std::string("bn_fwd.") + kGroupName[c.group], 0.0, bytes, s,
+            RUN(net, std::string("bn_fwd.") + kGroupName[c.group], 0.0, bytes, st,
                 launch_bn_eval_fwd(ws + g.y, g.M, c.cout, P + b.gamma, P + b.beta, R + b.rm,
-                                   R + b.rv, eps, residual, relu, ws + g.stats, ws + g.z, s));
+                                   R + b.rv, eps, residual, relu, ws + g.stats, ws + g.z, st));
         }
         return 0;
     };
@@ -1269,6 +1281,31 @@ static int forward_from_x4(cilrs_net* net, const cilrs_buffers* bufs, const floa
             const void* identity = bf16t ? (const void*)cur16 : (const void*)cur;
             const float* x = cur;
             const cilrs_half* x16 = cur16;
+            // The down-sample branch (1x1 / stride-2 convolution + BatchNorm: three short launches
+            // that leave most of the chip idle) depends on the block's input only: it is built on
+            // the side stream beside conv1 / bn1 / conv2, with column-partial scratch of its own
+            // and no split-K scratch; the block's last BatchNorm -- which adds it -- waits for it.
+            bool branch_pending = false;
+            const bool branch_aside = blk.down >= 0 && use_overlap(net) && bn_sync(net, ws, 0) == nullptr;
+            auto down_branch = [&](hipStream_t st, bool aside) -> int {
+                const ConvT& cd = A.convs[blk.down];
+                const ConvG& gd = net->cg[blk.down];
+                int nbd = 0;
+                net->side_branch = aside ? 1 : 0;
+                int rc = bf16t ? conv_fwd16(net, cd, gd, blk.down, cur16, ws, st, &nbd)
+                               : conv_fwd(net, cd, gd, cur, cd.cin, P + cd.w, ws + gd.y, ws, st, &nbd);
+                net->side_branch = 0;
+                if (rc) return 1;
+                if (bn(blk.down, nullptr, 0, nbd, st, aside)) return 1;
+                identity = bf16t ? (const void*)h16(ws, net->z16[blk.down]) : (const void*)(ws + gd.z);
+                return 0;
+            };
+            if (branch_aside) {
+                if (gbuf_side_begin(net, s)) return 1;            // the side stream sees the block's input
+                if (down_branch(net->side[0], true)) return 1;
+                CILRS_HIP(hipEventRecord(net->branch_ev, net->side[0]));
+                branch_pending = true;
+            }
             for (int i = 0; i < nchain; ++i) {
                 const ConvT& c = A.convs[chain[i]];
                 const ConvG& g = net->cg[chain[i]];
@@ -1278,23 +1315,17 @@ static int forward_from_x4(cilrs_net* net, const cilrs_buffers* bufs, const floa
                 } else {
                     if (conv_fwd(net, c, g, x, c.cin, P + c.w, ws + g.y, ws, s, &nb)) return 1;
                 }
-                if (i == 0 && blk.down >= 0) {
+                if (i == 0 && blk.down >= 0 && !branch_aside) {
                     // (issued after conv1 so that both convolutions reading `cur` are adjacent)
                     if (bn(chain[0], nullptr, 1, nb)) return 1;
-                    const ConvT& cd = A.convs[blk.down];
-                    const ConvG& gd = net->cg[blk.down];
-                    nb = 0;
-                    if (bf16t) {
-                        if (conv_fwd16(net, cd, gd, blk.down, cur16, ws, s, &nb)) return 1;
-                    } else {
-                        if (conv_fwd(net, cd, gd, cur, cd.cin, P + cd.w, ws + gd.y, ws, s, &nb))
-                            return 1;
-                    }
-                    if (bn(blk.down, nullptr, 0, nb)) return 1;
-                    identity = bf16t ? (const void*)h16(ws, net->z16[blk.down]) : (const void*)(ws + gd.z);
+                    if (down_branch(s, false)) return 1;
                 } else if (i + 1 < nchain) {
                     if (bn(chain[i], nullptr, 1, nb)) return 1;
                 } else {
+                    if (branch_pending) {
+                        CILRS_HIP(hipStreamWaitEvent(s, net->branch_ev, 0));
+                        branch_pending = false;
+                    }
                     if (bn(chain[i], identity, 1, nb)) return 1;
                 }
                 x = ws + g.z;
