@@ -317,8 +317,8 @@ struct cilrs_net {
     bool streams_ready = false;
     hipStream_t side[1];                   // weight-gradient stream
     hipEvent_t fork_ev, gbuf_ev[kNumG], wprep_ev, branch_ev;
-    int side_branch = 0;                   // conv_fwd / conv_fwd16 are building a down-sample branch on the side stream:
-                                           // its own column-partial scratch, no split-K scratch
+    int side_branch = 0;                   // conv_fwd / conv_fwd16 are building a down-sample branch: no split-K scratch;
+                                           // 1 = on the side stream, with column-partial scratch of its own
     bool wprep_pending = false;            // this step's weight images are being built on the side stream
     bool gbuf_pending[kNumG] = {};
     int dy_pos = 0;
@@ -547,7 +547,7 @@ int conv_fwd(cilrs_net* net, const ConvT& c, const ConvG& g, const float* x, int
     a.tile_counters_cap = kTileCounters;
     a.force_cfg = -1;
     if (bn_nblk) {
-        a.bn_partial = ws + (net->side_branch ? net->bn_partial2 : net->bn_partial);
+        a.bn_partial = ws + (net->side_branch == 1 ? net->bn_partial2 : net->bn_partial);
         a.bn_nblk = bn_nblk; *bn_nblk = 0;
     }
     const double flops = 2.0 * g.M * c.cout * c.k * c.k * c.cin;
@@ -673,7 +673,7 @@ int conv_fwd16(cilrs_net* net, const ConvT& c, const ConvG& g, int ci, const cil
     ConvF16Args a;
     memset(&a, 0, sizeof(a));
     a.x = x16; a.w = h16(ws, net->w16_all) + c.w; a.y16 = y16_of(net, ws, ci);
-    a.bn_partial = ws + (net->side_branch ? net->bn_partial2 : net->bn_partial);
+    a.bn_partial = ws + (net->side_branch == 1 ? net->bn_partial2 : net->bn_partial);
     a.N = net->B; a.H = g.H; a.W = g.W; a.Cin = c.cin; a.Ho = g.Ho; a.Wo = g.Wo; a.Cout = c.cout;
     a.K = c.k; a.stride = c.stride; a.pad = c.pad; a.bf16 = 1;
     *bn_nblk = conv_f16_train_mtiles(a);
@@ -1291,7 +1291,10 @@ static int forward_from_x4(cilrs_net* net, const cilrs_buffers* bufs, const floa
                 const ConvT& cd = A.convs[blk.down];
                 const ConvG& gd = net->cg[blk.down];
                 int nbd = 0;
-                net->side_branch = aside ? 1 : 0;
+                // (1: beside the main stream, own partial scratch; 2: on the main stream -- in BOTH
+                //  cases without split-K, so that the plan, hence the summation order, of this
+                //  convolution does not depend on whether the streams overlap)
+                net->side_branch = aside ? 1 : 2;
                 int rc = bf16t ? conv_fwd16(net, cd, gd, blk.down, cur16, ws, st, &nbd)
                                : conv_fwd(net, cd, gd, cur, cd.cin, P + cd.w, ws + gd.y, ws, st, &nbd);
                 net->side_branch = 0;
