@@ -316,7 +316,8 @@ struct cilrs_net {
     bool overlap = true;
     bool streams_ready = false;
     hipStream_t side[1];                   // weight-gradient stream
-    hipEvent_t fork_ev, gbuf_ev[kNumG], wprep_ev, branch_ev;
+    hipEvent_t fork_ev, gbuf_ev[kNumG], wprep_ev, branch_ev, heads_ev;
+    bool heads_pending = false;            // the heads' weight gradients of this backward pass are on the side stream
     int side_branch = 0;                   // conv_fwd / conv_fwd16 are building a down-sample branch: no split-K scratch;
                                            // 1 = on the side stream, with column-partial scratch of its own
     bool wprep_pending = false;            // this step's weight images are being built on the side stream
@@ -463,6 +464,7 @@ int ensure_streams(cilrs_net* net) {
     CILRS_HIP(hipEventCreateWithFlags(&net->fork_ev, stream_event_flags()));
     CILRS_HIP(hipEventCreateWithFlags(&net->wprep_ev, stream_event_flags()));
     CILRS_HIP(hipEventCreateWithFlags(&net->branch_ev, stream_event_flags()));
+    CILRS_HIP(hipEventCreateWithFlags(&net->heads_ev, stream_event_flags()));
     net->streams_ready = true;
     return 0;
 }
@@ -1110,6 +1112,7 @@ void cilrs_net_destroy(cilrs_net* net) {
         (void)hipEventDestroy(net->fork_ev);
         (void)hipEventDestroy(net->wprep_ev);
         (void)hipEventDestroy(net->branch_ev);
+        (void)hipEventDestroy(net->heads_ev);
     }
     if (net && net->graph_exec) (void)hipGraphExecDestroy(net->graph_exec);
     delete net;
@@ -2327,6 +2330,10 @@ int cilrs_net_backward(cilrs_net* net, const cilrs_buffers* bufs, const float* d
     }
     // everything the side stream still runs (weight gradients, fused Adam launches) joins here
     if (gbuf_join_all(net, s)) return 1;
+    if (net->heads_pending) {
+        CILRS_HIP(hipStreamWaitEvent(s, net->heads_ev, 0));
+        net->heads_pending = false;
+    }
     if (net->fused_adam && use_overlap(net)) {
         CILRS_HIP(hipEventRecord(net->fork_ev, net->side[0]));
         CILRS_HIP(hipStreamWaitEvent(s, net->fork_ev, 0));
@@ -2378,11 +2385,23 @@ static int backward_heads(cilrs_net* net, const cilrs_buffers* bufs, const float
         g.A = dy; g.lda = dy_ld; g.B = P + l.w; g.ldb = l.in; g.C = dx; g.ldc = dx_ld;
         g.mask = act; g.ldmask = act_ld; g.mask_scale = scale; g.M = B; g.N = l.in; g.K = l.out;
     };
+    // mode 2 = weight + bias gradients: nothing on the main stream reads them -- they go to the side
+    // stream (idle at this point of the backward pass, and these launches occupy a handful of
+    // CUs), behind the output gradient they multiply; cilrs_net_backward joins them at its end
     auto run = [&](int mode, HGemmArgs& h, int n) -> int {
         h.ngroups = n; h.relu = 0; h.accumulate = 0; h.drop_p = 0.f; h.seed = 0;
         double fl = 0.0;
         for (int i = 0; i < n; ++i) fl += 2.0 * h.g[i].M * h.g[i].N * h.g[i].K;
-        RUN(net, "heads_bwd", fl, 0.0, s, launch_hgemm(mode, h, s));
+        hipStream_t st = s;
+        if (mode == 2 && use_overlap(net)) {
+            if (gbuf_side_begin(net, s)) return 1;
+            st = net->side[0];
+        }
+        RUN(net, "heads_bwd", fl, 0.0, st, launch_hgemm(mode, h, st));
+        if (st != s) {
+            CILRS_HIP(hipEventRecord(net->heads_ev, st));
+            net->heads_pending = true;
+        }
         return 0;
     };
     HGemmArgs h;
