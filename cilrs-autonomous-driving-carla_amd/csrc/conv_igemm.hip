@@ -723,20 +723,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_cols_kernel(const ConvArgs 
         sh = *reinterpret_cast<const f32x4*>(a.ch_shift + co);
     }
     if (a.bias) bias = *reinterpret_cast<const f32x4*>(a.bias + co);
-    for (int m = blockIdx.x * rows_per_block + rsub; m < row_end; m += rpi) {
-        const size_t o = (size_t)m * a.y_ld + co;
-        f32x4 acc[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-        int sidx = 0;
-        for (; sidx + 3 < splits; sidx += 4) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                acc[u] += *reinterpret_cast<const f32x4*>(part + (size_t)(sidx + u) * slab + o);
-        }
-        for (; sidx < splits; ++sidx)
-            acc[0] += *reinterpret_cast<const f32x4*>(part + (size_t)sidx * slab + o);
-        f32x4 v = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    // one row: everything after its operands are in registers (same arithmetic, same order, whatever
+    // the loop shape below)
+    auto finish_row = [&](const int m, const size_t o, f32x4 v, const f32x4 mk, const f32x4 ad,
+                          const f32x4 zz, const f32x4 yy) {
         if (a.ch_scale) v = v * sc + sh;
         if (a.bias) v += bias;
         if (a.relu) {
@@ -744,11 +734,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_cols_kernel(const ConvArgs 
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
         if (a.mask) {
-            const f32x4 mk = *reinterpret_cast<const f32x4*>(a.mask + (size_t)m * a.mask_ld + co);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = mk[e] > 0.f ? v[e] * a.mask_scale : 0.f;
         }
-        if (a.addend) v += *reinterpret_cast<const f32x4*>(a.addend + o);
+        if (a.addend) v += ad;
         if (a.relu_post) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
@@ -761,14 +750,70 @@ __global__ __launch_bounds__(256) void splitk_reduce_cols_kernel(const ConvArgs 
         } else {
             f32x4 g = v;
             if (a.bwd_relu) {
-                const f32x4 zz = *reinterpret_cast<const f32x4*>(a.bwd_z + o);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) g[e] = zz[e] > 0.f ? g[e] : 0.f;
             }
-            const f32x4 yy = *reinterpret_cast<const f32x4*>(a.bwd_y + o);
             s1 += g;
 #pragma unroll
             for (int e = 0; e < 4; ++e) s2[e] = fmaf(g[e], (yy[e] - mean[e]) * rstd[e], s2[e]);
+        }
+        (void)m;
+    };
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    int m = blockIdx.x * rows_per_block + rsub;
+    if (splits <= 4) {
+        // up to four slabs (the Winograd channel split: three): a thread's rows are few (three at
+        // layer3) and each is a chain of dependent round trips -- THREE rows per trip, every load
+        // of the trip in flight before the first use
+        // (two for the data-gradient form: with three it needs 136 registers, and a launch on the
+        //  critical path of the backward pass must fit NEXT to the weight-gradient workgroups that
+        //  occupy every CU -- ~110 registers and 13 KB of LDS are what they leave.  Measured: the
+        //  136-register version, equally fast alone, made the overlapped step 0.56 ms SLOWER.)
+        constexpr int U = MODE == 1 ? 2 : 3;
+        for (; m < row_end; m += U * rpi) {
+            f32x4 sl[U][4], mk[U], ad[U], zz[U], yy[U];
+            size_t o[U];
+            bool live[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int mu = m + u * rpi;
+                live[u] = mu < row_end;
+                o[u] = (size_t)(live[u] ? mu : m) * a.y_ld + co;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    sl[u][k] = k < splits ? *reinterpret_cast<const f32x4*>(part + (size_t)k * slab + o[u]) : zero4;
+                mk[u] = a.mask ? *reinterpret_cast<const f32x4*>(a.mask + (size_t)(live[u] ? mu : m) * a.mask_ld + co) : zero4;
+                ad[u] = a.addend ? *reinterpret_cast<const f32x4*>(a.addend + o[u]) : zero4;
+                zz[u] = (MODE == 1 && a.bwd_relu) ? *reinterpret_cast<const f32x4*>(a.bwd_z + o[u]) : zero4;
+                yy[u] = MODE == 1 ? *reinterpret_cast<const f32x4*>(a.bwd_y + o[u]) : zero4;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (!live[u]) continue;
+                const f32x4 v = (sl[u][0] + sl[u][1]) + (sl[u][2] + sl[u][3]);
+                finish_row(m + u * rpi, o[u], v, mk[u], ad[u], zz[u], yy[u]);
+            }
+        }
+    } else {
+        for (; m < row_end; m += rpi) {
+            const size_t o = (size_t)m * a.y_ld + co;
+            f32x4 acc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = zero4;
+            int sidx = 0;
+            for (; sidx + 3 < splits; sidx += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    acc[u] += *reinterpret_cast<const f32x4*>(part + (size_t)(sidx + u) * slab + o);
+            }
+            for (; sidx < splits; ++sidx)
+                acc[0] += *reinterpret_cast<const f32x4*>(part + (size_t)sidx * slab + o);
+            const f32x4 v = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+            const f32x4 mk = a.mask ? *reinterpret_cast<const f32x4*>(a.mask + (size_t)m * a.mask_ld + co) : zero4;
+            const f32x4 ad = a.addend ? *reinterpret_cast<const f32x4*>(a.addend + o) : zero4;
+            const f32x4 zz = (MODE == 1 && a.bwd_relu) ? *reinterpret_cast<const f32x4*>(a.bwd_z + o) : zero4;
+            const f32x4 yy = MODE == 1 ? *reinterpret_cast<const f32x4*>(a.bwd_y + o) : zero4;
+            finish_row(m, o, v, mk, ad, zz, yy);
         }
     }
 #pragma unroll
